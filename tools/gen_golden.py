@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own module (build container only).
+
+Runs only where /root/reference exists (never on the GPU box, never from tests).
+It loads `/root/reference/vltk/modeling/frcnn.py` under stub modules, following
+the recipe recorded in SURVEY.md §8c: the reference's package `__init__` cannot
+be imported (datasets version skew, missing cv2/wget/torchvision), so `vltk`,
+`vltk.compat`, `vltk.decorators` and the three torchvision entry points are
+registered as stubs in `sys.modules`; everything else executed is the
+reference's own arithmetic.  The torchvision ops are the restatements in
+oracle/tv_ops.c (PARITY UNPINNED for those three ops).
+
+Nothing is copied from the reference: the outputs are data (inputs, seeds,
+expected tensors) written to tests/golden/*.npz.  Large weights are never
+stored -- they are regenerated from (config, seed) by vltk_amd.weights.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import frcnn_oracle as orc          # noqa: E402  (tv-op restatements)
+from vltk_amd.config import Config, vg_c4_config_dict   # noqa: E402
+from vltk_amd.weights import make_state_dict, synthetic_images   # noqa: E402
+
+REF = "/root/reference/vltk/modeling/frcnn.py"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class _RoIPool(torch.nn.Module):
+    def __init__(self, output_size, spatial_scale):
+        super().__init__()
+        self.output_size = output_size
+        self.spatial_scale = spatial_scale
+
+    def forward(self, x, rois):
+        size = self.output_size[0] if isinstance(self.output_size, (tuple, list)) else self.output_size
+        return orc.roi_pool(x, rois, size, self.spatial_scale)
+
+
+def _stable_sorted_nms(boxes, scores, thr):
+    return orc.nms(boxes, scores, thr)
+
+
+def load_reference():
+    def _offline(*a, **k):
+        raise EnvironmentError("offline: fetch-by-name loaders are not available")
+
+    tv, ops, bx = (types.ModuleType(n) for n in ("torchvision", "torchvision.ops", "torchvision.ops.boxes"))
+    ops.RoIPool, bx.nms, bx.batched_nms = _RoIPool, _stable_sorted_nms, orc.batched_nms
+    ops.boxes, tv.ops = bx, ops
+    vp = types.ModuleType("vltk")
+    vp.__path__ = []
+    vp.decorators = types.ModuleType("vltk.decorators")
+    vc = types.ModuleType("vltk.compat")
+    vc.WEIGHTS_NAME = "pytorch_model.bin"
+    vc.Config = Config
+    for n in ("cached_path", "hf_bucket_url", "is_remote_url", "load_checkpoint"):
+        setattr(vc, n, _offline)
+    sys.modules.update({"torchvision": tv, "torchvision.ops": ops, "torchvision.ops.boxes": bx,
+                        "vltk": vp, "vltk.decorators": vp.decorators, "vltk.compat": vc})
+    spec = importlib.util.spec_from_file_location("ref_frcnn", REF)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    return ref
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def tie_free(x, what):
+    v = np.sort(np.asarray(x).reshape(-1))
+    assert (np.diff(v) != 0).all(), f"{what}: ties present -- pick another seed"
+
+
+# ---------------------------------------------------------------------------
+def kat_ops(ref):
+    """Per-op known-answer vectors from the reference's classes (tiny shapes, weights stored)."""
+    g = torch.Generator().manual_seed(20260101)
+    out = {}
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g) * scale
+
+    def fill_bn(conv):
+        c = conv.norm.num_features
+        conv.norm.weight.data = torch.rand(c, generator=g) + 0.5
+        conv.norm.bias.data = rnd(c, scale=0.1)
+        conv.norm.running_mean.data = rnd(c, scale=0.1)
+        conv.norm.running_var.data = torch.rand(c, generator=g) + 0.5
+
+    def dump_sd(prefix, mod):
+        for k, v in mod.state_dict().items():
+            out[f"{prefix}/sd/{k}"] = np_(v)
+
+    # -- stem (caffe max-pool, ceil_mode) on odd sizes
+    for tag, caffe, hw in (("stem_caffe", True, (63, 95)), ("stem_pad1", False, (64, 96))):
+        stem = ref.BasicStem(3, 16, "BN", caffe_maxpool=caffe).eval()
+        stem.conv1.weight.data = rnd(16, 3, 7, 7, scale=0.1)
+        fill_bn(stem.conv1)
+        x = rnd(2, 3, *hw, scale=50.0)
+        out[f"{tag}/x"] = np_(x)
+        out[f"{tag}/y"] = np_(stem(x.clone()))
+        dump_sd(tag, stem)
+
+    # -- bottlenecks: (cin, cout, mid, stride, groups, stride_in_1x1, dilation)
+    for tag, a in {
+        "blk_s2_in1x1": (32, 64, 16, 2, 1, True, 1),
+        "blk_s2_in3x3": (32, 64, 16, 2, 1, False, 1),
+        "blk_identity": (64, 64, 16, 1, 1, True, 1),
+        "blk_dil2": (32, 64, 32, 1, 1, True, 2),
+        "blk_groups": (32, 64, 32, 1, 8, False, 1),
+    }.items():
+        cin, cout, mid, stride, groups, s1x1, dil = a
+        blk = ref.BottleneckBlock(cin, cout, bottleneck_channels=mid, stride=stride, num_groups=groups,
+                                  norm="BN", stride_in_1x1=s1x1, dilation=dil).eval()
+        for name in ("shortcut", "conv1", "conv2", "conv3"):
+            conv = getattr(blk, name)
+            if conv is None:
+                continue
+            fan = conv.weight[0].numel()
+            conv.weight.data = rnd(*conv.weight.shape, scale=(2.0 / fan) ** 0.5)
+            fill_bn(conv)
+        x = rnd(2, cin, 13, 18)
+        out[f"{tag}/x"] = np_(x)
+        out[f"{tag}/y"] = np_(blk(x.clone()))
+        out[f"{tag}/args"] = np.asarray([cin, cout, mid, stride, groups, int(s1x1), dil])
+        dump_sd(tag, blk)
+
+    # -- anchors (frcnn.py:1406-1510): two grid sizes, default sizes/ratios
+    cfg = Config(vg_c4_config_dict())
+    ag = ref.AnchorGenerator(cfg, [ref.ShapeSpec(channels=8, stride=16)])
+    out["anchors/cell"] = np_(ag.cell_anchors[0])
+    for hw in ((3, 4), (10, 14)):
+        a = ag([torch.zeros(2, 8, *hw)])
+        out[f"anchors/grid_{hw[0]}x{hw[1]}"] = np_(a[0, 0])
+        assert a.shape == (2, 1, hw[0] * hw[1] * 15, 4)
+
+    # -- apply_deltas incl. the scale clamp and k>1 class-specific deltas
+    for tag, w in (("deltas_rpn", (1.0, 1.0, 1.0, 1.0)), ("deltas_roi", (10.0, 10.0, 5.0, 5.0))):
+        t = ref.Box2BoxTransform(weights=w)
+        boxes = torch.rand(64, 4, generator=g) * 200
+        boxes[:, 2:] += boxes[:, :2] + 1.0
+        d = rnd(64, 12, scale=2.0)
+        d[0, :4] = torch.tensor([0.1, -0.2, 10.0, 0.5]) * torch.tensor(w)
+        boxes[0] = torch.tensor([0.0, 0.0, 16.0, 16.0])
+        out[f"{tag}/boxes"], out[f"{tag}/deltas"] = np_(boxes), np_(d)
+        out[f"{tag}/y"] = np_(t.apply_deltas(d, boxes))
+
+    # -- RPN head + proposals (RPN.forward frcnn.py:1640-1673) on a small map
+    cfgd = vg_c4_config_dict()
+    cfgd["proposal_generator"]["hidden_channels"] = 32
+    cfgd["rpn"]["pre_nms_topk_test"] = 400
+    cfgd["rpn"]["post_nms_topk_test"] = 40
+    cfg_s = Config(cfgd)
+    rpn = ref.RPN(cfg_s, {"res4": ref.ShapeSpec(channels=48, stride=16)}).eval()
+    for name, sc in (("conv", 0.1), ("objectness_logits", 0.5), ("anchor_deltas", 0.08)):
+        m = getattr(rpn.rpn_head, name)
+        m.weight.data = rnd(*m.weight.shape, scale=sc)
+        m.bias.data = rnd(*m.bias.shape, scale=0.05)
+    feat = torch.relu(rnd(2, 48, 9, 13))
+    shapes = torch.tensor([[144, 208], [130, 190]])
+    images = torch.zeros(2, 3, 144, 208)
+    with torch.no_grad():
+        obj, dlt = rpn.rpn_head([feat])
+        tie_free(np_(obj[0]), "rpn kat logits")
+        pb, lg = rpn(images, shapes, {"res4": feat})
+    out["rpn/feat"], out["rpn/shapes"] = np_(feat), np_(shapes)
+    out["rpn/objectness"], out["rpn/deltas"] = np_(obj[0]), np_(dlt[0])
+    for i in range(2):
+        out[f"rpn/boxes_{i}"], out[f"rpn/logits_{i}"] = np_(pb[i]), np_(lg[i])
+    dump_sd("rpn", rpn)
+
+    # -- predictor (FastRCNNOutputLayers frcnn.py:1676-1740), tiny
+    pred = ref.FastRCNNOutputLayers(64, 10, False, use_attr=True, num_attrs=5).eval()
+    for n_, p in pred.named_parameters():
+        p.data = rnd(*p.shape, scale=0.3)
+    f = torch.relu(rnd(12, 64))
+    with torch.no_grad():
+        s, a, d = pred(f)
+    out["pred/x"], out["pred/scores"], out["pred/attr"], out["pred/deltas"] = np_(f), np_(s), np_(a), np_(d)
+    dump_sd("pred", pred)
+
+    # -- ROIOutputs.inference (frcnn.py:1262-1294) incl. the threshold-list retry of do_nms
+    cfgd = vg_c4_config_dict()
+    cfgd["roi_heads"]["num_classes"] = 10
+    cfgd["roi_box_head"]["num_attrs"] = 5
+    cfgd["min_detections"], cfgd["max_detections"] = 6, 8
+    ro = ref.ROIOutputs(Config(cfgd))
+    ro.nms_thresh = [0.05, 0.3, 0.9]
+    R = [20, 17]
+    props = []
+    for r in R:
+        b = torch.rand(r, 4, generator=g) * 80
+        b[:, 2:] = b[:, :2] + 20 + torch.rand(r, 2, generator=g) * 60
+        props.append(b)
+    K = sum(R)
+    obj_logits, attr_logits = rnd(K, 11, scale=3.0), rnd(K, 6, scale=3.0)
+    box_deltas, feats = rnd(K, 40, scale=1.0), torch.relu(rnd(K, 16))
+    sizes = [(120, 160), (100, 150)]
+    scales = torch.tensor([[1.5, 2.0], [0.5, 0.75]])
+    for tag, sc in (("roiout", None), ("roiout_scaled", scales)):
+        res = ro(obj_logits, attr_logits, box_deltas, [p.clone() for p in props], feats, sizes, scales=sc)
+        for name, lst in zip(("boxes", "classes", "probs", "attrs", "attr_probs", "feats"), res):
+            for i, t in enumerate(lst):
+                out[f"{tag}/{name}_{i}"] = np_(t)
+    out["roiout/obj_logits"], out["roiout/attr_logits"] = np_(obj_logits), np_(attr_logits)
+    out["roiout/box_deltas"], out["roiout/feats_in"] = np_(box_deltas), np_(feats)
+    out["roiout/sizes"], out["roiout/scales"] = np.asarray(sizes), np_(scales)
+    for i, p in enumerate(props):
+        out[f"roiout/props_{i}"] = np_(p)
+    out["roiout/nms_thresh"] = np.asarray(ro.nms_thresh)
+    np.savez_compressed(os.path.join(OUT, "kat_ops.npz"), **out)
+    print("kat_ops.npz:", len(out), "arrays")
+
+
+# ---------------------------------------------------------------------------
+def e2e(ref, name, n, h, w, shapes, post_topk, det, seed, depth=101):
+    """End-to-end FRCNN.forward on small images with seeded R101 weights (weights NOT stored)."""
+    cfgd = vg_c4_config_dict(depth=depth, post_nms_topk=post_topk, detections=det)
+    cfg = Config(cfgd)
+    sd = make_state_dict(cfg, seed=seed)
+    net = ref.FRCNN(cfg).eval()
+    net.load_state_dict(to_torch_sd(sd), strict=True)
+    images = torch.from_numpy(synthetic_images(n, h, w, seed=seed))
+    shp = torch.tensor(shapes)
+    for i, (hh, ww) in enumerate(shapes):      # zero-pad beyond the content, like Preprocess does
+        images[i, :, hh:, :] = 0
+        images[i, :, :, ww:] = 0
+    stages = {}
+    hooks = [
+        net.backbone.register_forward_hook(lambda m, i, o: stages.__setitem__("res4", o["res4"])),
+        net.proposal_generator.rpn_head.register_forward_hook(
+            lambda m, i, o: stages.update(obj=o[0][0], dlt=o[1][0])),
+        net.proposal_generator.register_forward_hook(lambda m, i, o: stages.update(pboxes=o[0], plogits=o[1])),
+        net.roi_heads.register_forward_hook(
+            lambda m, i, o: stages.update(obj_logits=o[0], attr_logits=o[1], box_deltas=o[2], pooled=o[3])),
+        net.roi_heads.pooler.register_forward_hook(lambda m, i, o: stages.__setitem__("roipool", o)),
+    ]
+    with torch.no_grad():
+        o = net(images, shp)
+    for hk in hooks:
+        hk.remove()
+    tie_free(np_(stages["obj"]), f"{name} rpn logits")
+    out = {"images_seed": np.asarray(seed), "shapes": np.asarray(shapes), "nhw": np.asarray([n, h, w]),
+           "post_topk": np.asarray(post_topk), "det": np.asarray(det), "depth": np.asarray(depth),
+           "weights_seed": np.asarray(seed)}
+    out["res4"] = np_(stages["res4"])
+    out["rpn_objectness"], out["rpn_deltas"] = np_(stages["obj"]), np_(stages["dlt"])
+    for i in range(n):
+        out[f"proposal_boxes_{i}"], out[f"proposal_logits_{i}"] = np_(stages["pboxes"][i]), np_(stages["plogits"][i])
+        for k in ("obj_ids", "obj_probs", "attr_ids", "attr_probs", "boxes", "roi_features"):
+            out[f"{k}_{i}"] = np_(o[k][i])
+    out["preds_per_image"] = np_(o["preds_per_image"])
+    out["roipool_c0_7"] = np_(stages["roipool"][:, :8])            # channel subset: the full tensor is too large
+    out["roipool_sum"] = np_(stages["roipool"].double().sum(dim=(2, 3)).float())
+    out["feature_pooled"] = np_(stages["pooled"])
+    out["obj_logits"], out["attr_logits"] = np_(stages["obj_logits"]), np_(stages["attr_logits"])
+    bd = stages["box_deltas"]
+    out["box_deltas_head"] = np_(bd[:, :256])                     # first 64 classes + a full-row checksum
+    out["box_deltas_rowsum"] = np_(bd.double().sum(1).float())
+    # score margins: how far the top-1 class is from the runner-up (index parity is margin-aware)
+    p = torch.softmax(stages["obj_logits"], -1)[:, :-1]
+    top2 = p.topk(2, dim=1).values
+    out["cls_margin"] = np_(top2[:, 0] - top2[:, 1])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "preds_per_image", out["preds_per_image"], "res4 |mean| %.3f max %.2f" %
+          (np.abs(out["res4"]).mean(), out["res4"].max()),
+          "feat max %.2f" % out["feature_pooled"].max(),
+          "n_props", [len(b) for b in stages["pboxes"]],
+          "distinct obj ids", len(np.unique(np.concatenate([out[f"obj_ids_{i}"] for i in range(n)]))),
+          "min cls margin %.2e" % out["cls_margin"].min())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    kat_ops(ref)
+    e2e(ref, "e2e_r101_small", n=2, h=160, w=224, shapes=[[160, 224], [144, 200]], post_topk=30, det=12, seed=1234)

@@ -1,0 +1,131 @@
+"""Config object + the build-owned Visual-Genome ResNet-101-C4 configuration.
+
+`Config` mirrors the semantics of the reference's nested attribute dict
+(reference: vltk/compat.py:114-135): nested dicts become nested `Config`s,
+every key is reachable as both `cfg.key` and `cfg.KEY`, and a `None` value is
+rejected with `ValueError` (compat.py:119-120).  Only LOCAL loading is offered
+(a directory holding `config.yaml`, or a direct path) -- the reference's
+fetch-by-name loaders (compat.py:181-235) need the network and are out of
+scope.
+
+The default values below are the public bottom-up-attention VG C4 config as
+recalled in SURVEY.md §8a-cfg (not verifiable offline); every key the
+reference model reads (vltk/modeling/frcnn.py:200-223, 1230-1237, 1312-1336,
+1414-1417, 1537, 1583-1607, 1747-1750) is present.
+"""
+import copy
+import os
+
+import yaml
+
+CONFIG_NAME = "config.yaml"          # reference: vltk/compat.py:81
+WEIGHTS_NAME = "pytorch_model.bin"   # reference: vltk/compat.py:80
+
+
+class Config:
+    """Nested dict -> attributes; both `key` and `KEY` resolve (compat.py:133-135)."""
+
+    def __init__(self, dictionary, name="root", level=0):
+        object.__setattr__(self, "_name", name)
+        object.__setattr__(self, "_level", level)
+        d = {}
+        for k, v in dictionary.items():
+            if v is None:
+                raise ValueError(f"config key '{k}' is None")
+            v = copy.deepcopy(v)
+            if isinstance(v, dict):
+                v = Config(v, name=k, level=level + 1)
+            d[k] = v
+            setattr(self, k, v)
+        object.__setattr__(self, "_pointer", d)
+
+    def __setattr__(self, key, val):
+        self.__dict__[key] = val
+        self.__dict__[key.upper()] = val
+        self.__dict__[key.lower()] = val
+        ptr = self.__dict__.get("_pointer")
+        if ptr is not None and not key.startswith("_"):
+            ptr[key.lower() if key.lower() in ptr else key] = val
+
+    def __repr__(self):
+        return str(list(self._pointer.keys()))
+
+    def to_dict(self):
+        out = {}
+        for k, v in self._pointer.items():
+            out[k] = v.to_dict() if isinstance(v, Config) else copy.deepcopy(v)
+        return out
+
+    def dump_yaml(self, file_name):
+        with open(file_name, "w") as f:
+            yaml.safe_dump(self.to_dict(), f)
+
+    @staticmethod
+    def load_yaml(path):
+        with open(path) as f:
+            return yaml.load(f, Loader=yaml.SafeLoader)
+
+    @classmethod
+    def from_pretrained(cls, path, **kwargs):
+        """Local-only counterpart of compat.py:181-202."""
+        if os.path.isdir(path):
+            path = os.path.join(path, CONFIG_NAME)
+        if not os.path.isfile(path):
+            raise EnvironmentError(
+                f"Can't load config for '{path}': only local files/directories are "
+                "supported (fetch-by-name needs the network)")
+        return cls(cls.load_yaml(path))
+
+
+def vg_c4_config_dict(depth=101, num_groups=1, width_per_group=64,
+                      post_nms_topk=300, detections=36, device="cpu"):
+    """The build-owned config (lower-case keys so both cases resolve)."""
+    return {
+        "model": {
+            "device": device,
+            "pixel_mean": [102.9801, 115.9465, 122.7717],
+            "pixel_std": [1.0, 1.0, 1.0],
+            "max_pool": True,
+        },
+        "input": {"min_size_test": 800, "max_size_test": 1333, "format": "BGR"},
+        "size_divisibility": 0,
+        "pad_value": 0.0,
+        "resnets": {
+            "norm": "BN", "stem_out_channels": 64, "out_features": ["res4"],
+            "depth": depth, "num_groups": num_groups, "width_per_group": width_per_group,
+            "res2_out_channels": 256, "stride_in_1x1": True, "res5_dilation": 1,
+        },
+        "backbone": {"freeze_at": 2},
+        "anchor_generator": {
+            "sizes": [[32, 64, 128, 256, 512]],
+            "aspect_ratios": [[0.5, 1.0, 2.0]],
+            "offset": 0.0,
+        },
+        "proposal_generator": {"hidden_channels": 512, "min_size": 0},
+        "rpn": {
+            "in_features": ["res4"], "nms_thresh": 0.7,
+            "batch_size_per_image": 256, "positive_fraction": 0.5,
+            "smooth_l1_beta": 0.0, "loss_weight": 1.0,
+            "pre_nms_topk_train": 12000, "pre_nms_topk_test": 6000,
+            "post_nms_topk_train": 2000, "post_nms_topk_test": post_nms_topk,
+            "boundary_thresh": 0, "bbox_reg_weights": [1.0, 1.0, 1.0, 1.0],
+            "iou_thresholds": [0.3, 0.7], "iou_labels": [0, -1, 1],
+        },
+        "roi_heads": {
+            "in_features": ["res4"], "num_classes": 1600, "positive_fraction": 0.25,
+            "proposal_append_gt": True, "score_thresh_test": 0.05,
+            "nms_thresh_test": 0.3,
+        },
+        "roi_box_head": {
+            "smooth_l1_beta": 0.0, "bbox_reg_weights": [10.0, 10.0, 5.0, 5.0],
+            "cls_agnostic_bbox_reg": False, "pooler_resolution": 14,
+            "pooler_sampling_ratio": 2, "res5halve": False, "attr": True,
+            "num_attrs": 400,
+        },
+        "min_detections": detections,
+        "max_detections": detections,
+    }
+
+
+def vg_c4_config(**kw):
+    return Config(vg_c4_config_dict(**kw))
