@@ -1,0 +1,238 @@
+/*
+ * vltk_hip.h -- C ABI of libvltk_hip.so: the MI355X (gfx950) implementation of
+ * vltk's Faster R-CNN visual-feature extraction forward pass.
+ *
+ * This is the drop-in boundary.  The reference has no native layer (it is
+ * pure Python over torch/torchvision), so every entry point below replaces a
+ * Python-level interface of /root/reference/vltk/modeling/frcnn.py; the
+ * file:line each one stands in for is given per function.  A maintainer binds
+ * these with ctypes; vltk_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - Every function returns an int status: VK_OK (0) or a VK_E* code;
+ *     vk_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are device (HBM) pointers owned by the caller; "host"
+ *     pointers are ordinary host memory.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).
+ *   - Activations are NHWC ("pixel-major": a feature map is a row-major
+ *     [N*H*W, C] matrix), dtype per vk_dtype; boxes are (x1,y1,x2,y2) f32.
+ */
+#ifndef VLTK_HIP_H
+#define VLTK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_OK 0
+#define VK_EINVAL 1      /* bad argument / unsupported configuration  -> ValueError      */
+#define VK_ENOTIMPL 2    /* reference raises NotImplementedError (frcnn.py:1930)         */
+#define VK_ENONFINITE 3  /* non-finite box: reference's assert in _clip_box (frcnn.py:148) -> AssertionError */
+#define VK_EWEIGHTS 4    /* missing / mis-shaped weight (strict load, frcnn.py:1881)     -> OSError */
+#define VK_EHIP 5        /* HIP runtime failure                                          -> RuntimeError */
+#define VK_ENOMEM 6
+
+typedef enum { VK_F32 = 0, VK_F16 = 1, VK_I64 = 2, VK_I32 = 3 } vk_dtype;
+
+#define VK_MAX_ANCHOR_DIM 8
+#define VK_MAX_NMS_THRESH 8
+
+/* The config keys the reference model reads (frcnn.py:200-223,
+ * 1230-1237, 1312-1336, 1414-1417, 1537, 1583-1607). */
+typedef struct vk_config {
+    int32_t depth;                 /* RESNETS.DEPTH 50|101|152 */
+    int32_t num_groups;            /* RESNETS.NUM_GROUPS (only 1 supported this round) */
+    int32_t width_per_group;       /* RESNETS.WIDTH_PER_GROUP */
+    int32_t stem_out_channels;     /* RESNETS.STEM_OUT_CHANNELS */
+    int32_t res2_out_channels;     /* RESNETS.RES2_OUT_CHANNELS */
+    int32_t stride_in_1x1;         /* RESNETS.STRIDE_IN_1X1 */
+    int32_t caffe_maxpool;         /* MODEL.MAX_POOL */
+    int32_t num_sizes;             /* ANCHOR_GENERATOR.SIZES[0] */
+    float   sizes[VK_MAX_ANCHOR_DIM];
+    int32_t num_ratios;            /* ANCHOR_GENERATOR.ASPECT_RATIOS[0] */
+    float   ratios[VK_MAX_ANCHOR_DIM];
+    float   anchor_offset;         /* ANCHOR_GENERATOR.OFFSET */
+    int32_t rpn_hidden_channels;   /* PROPOSAL_GENERATOR.HIDDEN_CHANNELS (-1 = same as res4) */
+    float   rpn_min_size;          /* PROPOSAL_GENERATOR.MIN_SIZE */
+    double  rpn_nms_thresh;        /* RPN.NMS_THRESH */
+    int32_t pre_nms_topk;          /* RPN.PRE_NMS_TOPK_TEST  (<= 8192) */
+    int32_t post_nms_topk;         /* RPN.POST_NMS_TOPK_TEST (<= 1024) */
+    float   rpn_bbox_weights[4];   /* RPN.BBOX_REG_WEIGHTS */
+    int32_t num_classes;           /* ROI_HEADS.NUM_CLASSES */
+    int32_t num_attrs;             /* ROI_BOX_HEAD.NUM_ATTRS */
+    int32_t use_attr;              /* ROI_BOX_HEAD.ATTR */
+    int32_t pooler_resolution;     /* ROI_BOX_HEAD.POOLER_RESOLUTION */
+    int32_t res5_halve;            /* ROI_BOX_HEAD.RES5HALVE (only 0 supported this round) */
+    int32_t cls_agnostic_bbox_reg; /* ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG */
+    float   roi_bbox_weights[4];   /* ROI_BOX_HEAD.BBOX_REG_WEIGHTS */
+    int32_t precision;             /* VK_F16: fp16 storage / fp32 accumulate (fast);
+                                      VK_F32: fp32 storage, exact-f32 MFMA (strict parity mode) */
+} vk_config;
+
+/* Per-call knobs = the mutable attributes of the reference's model.roi_outputs
+ * (frcnn.py:1229-1240; set by callers, tests/frcnn_test.py:16-19). */
+typedef struct vk_roi_params {
+    int32_t num_nms_thresh;
+    double  nms_thresh[VK_MAX_NMS_THRESH];
+    int32_t min_detections;
+    int32_t max_detections;
+} vk_roi_params;
+
+/* Device output block of one forward (caller-allocated, fixed capacity D =
+ * max_detections per image; rows >= preds_per_image[n] are zero).  Mirrors the
+ * OrderedDict returned by FRCNN.inference (frcnn.py:1996-2004). */
+typedef struct vk_outputs {
+    int64_t *obj_ids;          /* [N, D]        */
+    float   *obj_probs;        /* [N, D]        */
+    int64_t *attr_ids;         /* [N, D]        */
+    float   *attr_probs;       /* [N, D]        */
+    float   *boxes;            /* [N, D, 4]     */
+    int64_t *preds_per_image;  /* [N]           */
+    float   *roi_features;     /* [N, D, 2048]  */
+} vk_outputs;
+
+typedef struct vk_handle vk_handle;
+
+const char *vk_last_error(void);
+int vk_version(void);
+
+/* ---- model lifetime ------------------------------------------------------
+ * vk_create        <- FRCNN.__init__            frcnn.py:1744-1755 (build_backbone :200-261,
+ *                                               RPN :1580-1610, Res5ROIHeads :1312-1363)
+ * vk_load_weights  <- load_state_dict, one call per state-dict tensor, reference key names
+ *                                               frcnn.py:1862-1881
+ * vk_finalize      <- model.eval() + BN folding / NHWC repack (frcnn.py:1920; Conv2d :794-822)
+ * vk_destroy       <- Python GC
+ */
+int vk_create(const vk_config *cfg, int device, vk_handle **out);
+int vk_load_weights(vk_handle *h, const char *name, const void *host_ptr,
+                    const int64_t *shape, int ndim, vk_dtype dtype);
+int vk_finalize(vk_handle *h);
+int vk_destroy(vk_handle *h);
+
+/* Tunables.  "head_chunk": RoIs per Res5-head chunk (0 = all RoIs in one pass; default 64 or
+ * the VK_HEAD_CHUNK environment variable).  Results do not depend on it. */
+int vk_set_option(vk_handle *h, const char *key, int value);
+
+/* Number of weight tensors the model expects and their names (strict load). */
+int vk_num_weights(vk_handle *h, int *count);
+int vk_weight_name(vk_handle *h, int index, const char **name);
+
+/* ---- the forward pass ----------------------------------------------------
+ * vk_forward <- FRCNN.forward / inference   frcnn.py:1924-2004
+ *   images_dev : [N,3,H,W] f32 NCHW, already resized / mean-subtracted / zero-padded
+ *   image_hw   : host [N,2] int32 (h, w) of the un-padded content   (image_shapes)
+ *   scales_yx  : host [N,2] f32 or NULL                              (frcnn.py:1280-1283)
+ * Asynchronous on `stream` except for one small device->host read of the
+ * non-finite flag at the end (the reference asserts on host, frcnn.py:148).
+ */
+int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W,
+               const int32_t *image_hw, const float *scales_yx,
+               const vk_roi_params *rp, const vk_outputs *out_dev, void *stream);
+
+/* Intermediate tensors of the last forward, for stage-level parity tests.
+ * name in {"res4","rpn_out","proposal_boxes","proposal_logits",
+ * "proposal_counts","pooled","feature_pooled","obj_logits","attr_logits","chosen_deltas","keep_ids"};
+ * "rpn_out" is the fused RPN head output [N,Hf,Wf,ld]: columns [0,A) objectness, [A,5A) deltas.
+ * Returns a device pointer owned by the handle (valid until the next forward),
+ * its dtype and its shape (up to 4 dims). */
+int vk_get_stage(vk_handle *h, const char *name, const void **dev_ptr,
+                 vk_dtype *dtype, int64_t *shape, int *ndim);
+
+/* device->device copy on `stream` (lets a binding copy a stage tensor into memory it owns). */
+int vk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream);
+
+/* timing of the last forward's stages (HIP events on the launch stream), ms:
+ * [0] backbone [1] rpn head [2] proposals [3] roi pool+res5 head [4] predictor+outputs [5] total.
+ * Only recorded when enabled (costs event records, no syncs in the timed path). */
+int vk_enable_stage_timing(vk_handle *h, int enable);
+int vk_get_stage_timing(vk_handle *h, float *ms6);
+
+/* ---- stage-level entry points (tests, micro-benchmarks) -------------------
+ * All pointers are device pointers unless marked host.                      */
+
+/* Packed-weight helpers (host side).  K is ordered (kh, kw, cin) and padded to
+ * whole 128-byte K-tiles; rows are padded to a multiple of 128 output channels. */
+size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, vk_dtype dt);
+int vk_packed_cout(int cout);
+/* w_oihw [cout,cin,kh,kw] f32; bn = {gamma,beta,mean,var} each [cout] or NULL;
+ * bias [cout] or NULL; outputs: packed weights (dtype dt) and f32 bias [vk_packed_cout]. */
+int vk_pack_conv_weight(const float *w_oihw_host, const float *bn_host, const float *bias_host,
+                        int cout, int cin, int kh, int kw, vk_dtype dt,
+                        void *w_packed_host, float *bias_packed_host);
+
+/* conv + folded-BN bias (+ residual) (+ ReLU)  <- Conv2d.forward frcnn.py:794-822,
+ * BottleneckBlock.forward :963-979.  x [N,H,W,cin] (dt), residual/y [N*Ho*Wo, ldy]. */
+int vk_conv2d(const void *x, int N, int H, int W, int cin,
+              const void *w_packed, const float *bias_packed, const void *residual,
+              void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil,
+              int relu, vk_dtype dt, vk_dtype out_dt, void *stream);
+
+/* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
+int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);
+int vk_nhwc_to_nchw(const void *x, int N, int C, int H, int W, float *y, vk_dtype dt, void *stream);
+
+/* stem: 7x7 s2 p3 conv + BN + ReLU + max-pool  <- BasicStem.forward frcnn.py:872-879.
+ * x NCHW f32 [N,3,H,W]; w_packed from vk_pack_stem_weight; y NHWC [N,Hp,Wp,cout]. */
+size_t vk_packed_stem_bytes(int cout, vk_dtype dt);
+int vk_pack_stem_weight(const float *w_oihw_host, const float *bn_host, int cout, vk_dtype dt,
+                        void *w_packed_host, float *bias_packed_host);
+int vk_stem(const float *x, int N, int H, int W, const void *w_packed, const float *bias_packed,
+            int cout, int caffe_maxpool, void *y, vk_dtype dt, void *workspace, size_t workspace_bytes,
+            void *stream);
+size_t vk_stem_workspace_bytes(int N, int H, int W, int cout, vk_dtype dt);
+void vk_stem_out_hw(int H, int W, int caffe_maxpool, int *Ho, int *Wo);
+
+/* max-pool 3x3 s2 (ceil_mode pad 0, or pad 1)  <- frcnn.py:875-878 */
+int vk_maxpool3x3s2(const void *x, int N, int H, int W, int C, int caffe, void *y, vk_dtype dt, void *stream);
+
+/* RPN proposals  <- RPNOutputs.predict_* frcnn.py:748-781, find_top_rpn_proposals :264-390,
+ * AnchorGenerator :1463-1510, Box2BoxTransform.apply_deltas :548-584, batched_nms (torchvision).
+ *   logits [N,Hf,Wf,A] f32, deltas [N,Hf,Wf,4A] f32 (row stride ld_* elements),
+ *   cell_anchors [A,4] f32, image_hw dev [N,2] i32.
+ *   out_boxes [N,post,4], out_logits [N,post], out_counts [N] i32, nonfinite_flag [1] i32. */
+size_t vk_rpn_workspace_bytes(int N, int HWA, int pre_topk);
+int vk_rpn_proposals(const float *logits, int ld_logits, const float *deltas, int ld_deltas,
+                     int N, int Hf, int Wf, int A, const float *cell_anchors, int stride, float offset,
+                     const int32_t *image_hw, const float *bbox_weights4_host, float min_size,
+                     double nms_thresh, int pre_topk, int post_topk,
+                     float *out_boxes, float *out_logits, int32_t *out_counts, int32_t *nonfinite_flag,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Greedy NMS (torchvision.ops.nms semantics; frcnn.py:132): boxes [n,4], scores [n];
+ * keep_out [n] i64 in score order, count_out [1] i32. */
+int vk_nms(const float *boxes, const float *scores, int n, double thresh,
+           int64_t *keep_out, int32_t *count_out, void *workspace, size_t workspace_bytes, void *stream);
+size_t vk_nms_workspace_bytes(int n);
+
+/* RoIPool (torchvision.ops.RoIPool; frcnn.py:1179,1198): feat [N,H,W,C] NHWC, rois [K,5] f32
+ * -> out [K,P,P,C] NHWC. */
+int vk_roi_pool(const void *feat, int N, int H, int W, int C, const float *rois, int K,
+                float spatial_scale, int P, void *out, vk_dtype dt, void *stream);
+
+/* mean over the P*P positions of each RoI  <- frcnn.py:1401: x [K,S,C] (dt) -> out [K,C] f32 */
+int vk_mean_pool(const void *x, int K, int S, int C, float *out, vk_dtype dt, void *stream);
+
+/* Box2BoxTransform.apply_deltas (frcnn.py:548-584): deltas [M,4k], boxes [M,4] -> out [M,4k] */
+int vk_box_decode(const float *deltas, const float *boxes, int M, int k, const float *weights4_host,
+                  float *out, void *stream);
+
+/* ROIOutputs.inference (frcnn.py:1262-1294) + do_nms (:116-143), per image:
+ *   obj_logits [K,C+1] f32 (row stride ld_obj), attr_logits [K,A+1] f32 (ld_attr),
+ *   box_deltas: either full [K,4C] (ld_box=4C, chosen_only=0) or only the arg-max class's
+ *   4 deltas [K,4] (chosen_only=1), proposals [N,R,4] + counts [N], features [K,F] f32. */
+int vk_roi_outputs(const float *obj_logits, int ld_obj, const float *attr_logits, int ld_attr,
+                   const float *box_deltas, int ld_box, int chosen_only,
+                   const float *proposals, const int32_t *counts, const float *features, int F,
+                   int N, int R, int C, int A, const int32_t *image_hw, const float *scales_yx_dev,
+                   const float *weights4_host, const vk_roi_params *rp, const vk_outputs *out,
+                   int64_t *keep_ids_out, int32_t *nonfinite_flag, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLTK_HIP_H */

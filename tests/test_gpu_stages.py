@@ -1,0 +1,327 @@
+"""-m gpu: stage-level parity of the HIP kernels against the oracle, through the C ABI.
+
+Tolerances (metric: max|a-b| / max|ref|):
+  * convolution / GEMM, fp32 strict mode ...... 2e-5 (exact-f32 MFMA, different summation order)
+  * convolution / GEMM, fp16 fast mode ........ 1e-3 against the fp16-emulating oracle
+    (same fp16-rounded operands, fp32 accumulate; differences = summation order + one fp16 ulp)
+  * pooling, NMS, top-k, index outputs ........ bit-exact
+  * box decode ................................ 2e-6 (expf implementations differ by <= 1 ulp)
+"""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import frcnn_oracle as orc          # noqa: E402
+from oracle.frcnn_oracle import FRCNNOracle    # noqa: E402
+from vltk_amd import _lib as L                 # noqa: E402
+from vltk_amd.config import Config, vg_c4_config_dict   # noqa: E402
+
+import gpu_util as G                           # noqa: E402
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+CONV_CASES = [
+    # name, N,H,W, cin, cout, k, stride, pad, dil, residual, relu
+    ("1x1", 2, 13, 17, 64, 256, 1, 1, 0, 1, False, True),
+    ("1x1_narrow", 1, 20, 21, 64, 64, 1, 1, 0, 1, False, True),
+    ("1x1_s2", 2, 14, 19, 256, 128, 1, 2, 0, 1, False, False),
+    ("3x3", 2, 12, 15, 64, 64, 3, 1, 1, 1, False, True),
+    ("3x3_wide", 1, 9, 11, 128, 128, 3, 1, 1, 1, False, True),
+    ("3x3_dil2", 3, 14, 14, 128, 128, 3, 1, 2, 2, False, True),
+    ("1x1_res", 2, 10, 13, 128, 512, 1, 1, 0, 1, True, True),
+    ("3x3_s2", 1, 15, 16, 64, 128, 3, 2, 1, 1, False, True),
+    ("1x1_big", 1, 40, 50, 512, 256, 1, 1, 0, 1, False, True),   # 2000 rows: several pixel tiles + an edge tile
+]
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case, dt):
+    _, N, H, W, cin, cout, k, stride, pad, dil, use_res, relu = case
+    g = _rng(zlib.crc32(case[0].encode()))
+    x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = (g.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    res = torch.from_numpy(g.standard_normal((N, cout, Ho, Wo)).astype(np.float32)) if use_res else None
+    y = G.conv2d(x, w, bn=bn, residual_nchw=res, stride=stride, pad=pad, dil=dil, relu=relu, dt=dt)
+    wf, bf = G.fold_ref(w, bn, dt)
+    q = (lambda t: t.half().float()) if dt == L.VK_F16 else (lambda t: t)
+    ref = F.conv2d(q(x), wf, None, stride, pad, dil) + bf.view(1, -1, 1, 1)
+    if use_res:
+        ref = ref + q(res)
+    if relu:
+        ref = F.relu(ref)
+    ref = q(ref)
+    tol = 1e-3 if dt == L.VK_F16 else 2e-5
+    assert G.rel_err(y, ref) <= tol
+
+
+def test_conv_bias_f32_out():
+    """fp16 operands, fp32 output with bias and a channel count that is not a multiple of 8 (RPN heads: 75)."""
+    g = _rng(7)
+    x = torch.from_numpy(g.standard_normal((2, 128, 9, 13)).astype(np.float32))
+    w = (g.standard_normal((75, 128, 1, 1)) * 0.1).astype(np.float32)
+    b = g.standard_normal(75).astype(np.float32)
+    y = G.conv2d(x, w, bias=b, dt=L.VK_F16, out_dt=L.VK_F32)
+    ref = F.conv2d(x.half().float(), torch.from_numpy(w).half().float(), torch.from_numpy(b))
+    assert y.shape == ref.shape
+    assert G.rel_err(y, ref) <= 1e-5
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "kat_ops.npz"))
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("tag,caffe", [("stem_caffe", 1), ("stem_pad1", 0)])
+def test_stem(kat, tag, caffe, dt):
+    """BasicStem (7x7 s2 conv + BN + ReLU + max-pool) against the reference's own output (golden)."""
+    x = torch.from_numpy(kat[tag + "/x"])
+    sd = {k.split("/sd/")[1]: kat[k] for k in kat.files if k.startswith(tag + "/sd/")}
+    w = sd["conv1.weight"]
+    cout = w.shape[0]
+    bn = np.concatenate([sd["conv1.norm.weight"], sd["conv1.norm.bias"], sd["conv1.norm.running_mean"],
+                         sd["conv1.norm.running_var"]]).astype(np.float32)
+    wp = np.zeros(L.load().vk_packed_stem_bytes(cout, dt), dtype=np.uint8)
+    bp = np.zeros(L.load().vk_packed_cout(cout), dtype=np.float32)
+    L.call("vk_pack_stem_weight", np.ascontiguousarray(w).ctypes.data_as(C.c_void_p), bn.ctypes.data_as(C.c_void_p),
+           cout, dt, wp.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p))
+    wd, bd = torch.from_numpy(wp).to(G.DEV), torch.from_numpy(bp).to(G.DEV)
+    N, _, H, W = x.shape
+    ho, wo = C.c_int(), C.c_int()
+    L.load().vk_stem_out_hw(H, W, caffe, C.byref(ho), C.byref(wo))
+    ref = kat[tag + "/y"]
+    assert (ho.value, wo.value) == ref.shape[2:]
+    ws = torch.empty(L.load().vk_stem_workspace_bytes(N, H, W, cout, dt), dtype=torch.uint8, device=G.DEV)
+    y = torch.empty((N, ho.value, wo.value, cout), dtype=G.TDT[dt], device=G.DEV)
+    xd = x.to(G.DEV)
+    L.call("vk_stem", G.P(xd), N, H, W, G.P(wd), G.P(bd), cout, caffe, G.P(y), dt, G.P(ws), ws.numel(), G.stream())
+    out = G.to_nchw(y, dt)
+    if dt == L.VK_F32:
+        assert G.rel_err(out, ref) <= 2e-5
+    else:
+        d = vg_c4_config_dict()
+        d["model"]["max_pool"] = bool(caffe)
+        o = FRCNNOracle(Config(d), {"backbone.stem." + k: torch.from_numpy(v) for k, v in sd.items()}, emulate="fp16")
+        assert G.rel_err(out, o.stem(x)) <= 1e-3
+        assert G.rel_err(out, ref) <= 1e-2      # fp16 storage vs the fp32 reference (reported, loose)
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("hw,caffe", [((17, 23), 1), ((16, 22), 1), ((16, 22), 0), ((9, 9), 1)])
+def test_maxpool(hw, caffe, dt):
+    g = _rng(11)
+    x = torch.from_numpy(g.standard_normal((2, 16, *hw)).astype(np.float32))
+    if dt == L.VK_F16:
+        x = x.half().float()
+    ref = F.max_pool2d(x, 3, 2, 0, ceil_mode=True) if caffe else F.max_pool2d(x, 3, 2, 1)
+    xd = G.to_nhwc(x, dt)
+    y = torch.empty((2, ref.shape[2], ref.shape[3], 16), dtype=G.TDT[dt], device=G.DEV)
+    L.call("vk_maxpool3x3s2", G.P(xd), 2, hw[0], hw[1], 16, caffe, G.P(y), dt, G.stream())
+    np.testing.assert_array_equal(G.to_nchw(y, dt).numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+def test_roi_pool(dt):
+    """RoIPool incl. the edge cases torchvision defines: negative / oversize / degenerate boxes, .5 rounding."""
+    g = _rng(3)
+    N, Cc, H, W, Pp = 2, 32, 11, 15, 7
+    x = torch.from_numpy(g.standard_normal((N, Cc, H, W)).astype(np.float32))
+    if dt == L.VK_F16:
+        x = x.half().float()
+    rois = [
+        [0, 0, 0, 240, 176], [1, 8, 8, 8, 8], [0, -50, -30, 20, 40], [1, 100, 60, 400, 300],
+        [0, 24, 40, 8, 8],            # x2 < x1: malformed -> forced 1x1
+        [1, 8.0, 24.0, 56.0, 72.0],   # *1/16 -> exact .5 values (round half away from zero)
+        [0, 300, 300, 400, 400],      # completely outside -> empty bins -> 0
+        [1, 7.99, 8.01, 199.5, 130.2],
+    ]
+    for _ in range(24):
+        xs, ys = sorted(g.uniform(-20, 260, 2)), sorted(g.uniform(-20, 200, 2))
+        rois.append([int(g.integers(0, N)), xs[0], ys[0], xs[1], ys[1]])
+    r = np.asarray(rois, dtype=np.float32)
+    ref = orc.roi_pool(x, torch.from_numpy(r), Pp, 1.0 / 16)
+    xd = G.to_nhwc(x, dt)
+    rd = torch.from_numpy(r).to(G.DEV)
+    y = torch.empty((len(r), Pp, Pp, Cc), dtype=G.TDT[dt], device=G.DEV)
+    L.call("vk_roi_pool", G.P(xd), N, H, W, Cc, G.P(rd), len(r), 1.0 / 16, Pp, G.P(y), dt, G.stream())
+    np.testing.assert_array_equal(G.to_nchw(y, dt).numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+def test_mean_pool(dt):
+    g = _rng(5)
+    K, S, Cc = 5, 196, 2048
+    x = torch.from_numpy(g.standard_normal((K, S, Cc)).astype(np.float32))
+    if dt == L.VK_F16:
+        x = x.half().float()
+    xd = x.to(G.DEV, G.TDT[dt])
+    out = torch.empty((K, Cc), dtype=torch.float32, device=G.DEV)
+    L.call("vk_mean_pool", G.P(xd), K, S, Cc, G.P(out), dt, G.stream())
+    torch.cuda.synchronize()
+    assert G.rel_err(out.cpu(), x.mean(1)) <= 1e-6
+
+
+@pytest.mark.parametrize("tag,w", [("deltas_rpn", (1.0, 1.0, 1.0, 1.0)), ("deltas_roi", (10.0, 10.0, 5.0, 5.0))])
+def test_box_decode(kat, tag, w):
+    d = torch.from_numpy(kat[tag + "/deltas"]).to(G.DEV)
+    b = torch.from_numpy(kat[tag + "/boxes"]).to(G.DEV)
+    out = torch.empty_like(d)
+    L.call("vk_box_decode", G.P(d), G.P(b), d.shape[0], d.shape[1] // 4, (C.c_float * 4)(*w), G.P(out), G.stream())
+    torch.cuda.synchronize()
+    assert G.rel_err(out.cpu(), kat[tag + "/y"]) <= 2e-6
+
+
+def _nms_gpu(boxes, scores, thr):
+    n = len(boxes)
+    bd, sd_ = torch.from_numpy(boxes).to(G.DEV), torch.from_numpy(scores).to(G.DEV)
+    keep = torch.zeros(max(n, 1), dtype=torch.int64, device=G.DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=G.DEV)
+    ws = torch.empty(L.load().vk_nms_workspace_bytes(n), dtype=torch.uint8, device=G.DEV)
+    L.call("vk_nms", G.P(bd), G.P(sd_), n, float(thr), G.P(keep), G.P(cnt), G.P(ws), ws.numel(), G.stream())
+    torch.cuda.synchronize()
+    return keep[: int(cnt.item())].cpu().numpy()
+
+
+@pytest.mark.parametrize("n,thr,ties", [(1, 0.5, False), (37, 0.3, False), (300, 0.3, True), (1000, 0.7, True),
+                                        (6000, 0.7, False), (6000, 0.5, True)])
+def test_nms_bit_exact(n, thr, ties):
+    """Greedy NMS: kept indices identical to the oracle, incl. score ties (lower index first) and
+    clustered boxes (heavy suppression)."""
+    g = _rng(n * 7 + int(thr * 10))
+    ctr = g.uniform(0, 1300, (max(n // 20, 1), 2))
+    c = ctr[g.integers(0, len(ctr), n)] + g.normal(0, 25, (n, 2))
+    wh = g.uniform(8, 220, (n, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    scores = g.standard_normal(n).astype(np.float32)
+    if ties:
+        scores = np.round(scores * 4) / 4     # many exact ties
+    ref = orc.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).numpy()
+    got = _nms_gpu(boxes, scores, thr)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_nms_empty():
+    assert len(_nms_gpu(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.5)) == 0
+
+
+def _rpn_gpu(obj, dlt, shapes, cell, pre, post, thr, min_size=0.0):
+    """obj [N,A,H,W], dlt [N,4A,H,W] (oracle layout) -> GPU proposals via the C ABI."""
+    N, A, Hf, Wf = obj.shape
+    lg = obj.permute(0, 2, 3, 1).contiguous().to(G.DEV)            # [N,H,W,A]
+    dl = dlt.permute(0, 2, 3, 1).contiguous().to(G.DEV)            # [N,H,W,4A]
+    ca = torch.from_numpy(np.ascontiguousarray(cell, dtype=np.float32)).to(G.DEV)
+    hw = torch.tensor(shapes, dtype=torch.int32, device=G.DEV)
+    ob = torch.zeros((N, post, 4), dtype=torch.float32, device=G.DEV)
+    ol = torch.zeros((N, post), dtype=torch.float32, device=G.DEV)
+    oc = torch.zeros((N,), dtype=torch.int32, device=G.DEV)
+    flag = torch.zeros((1,), dtype=torch.int32, device=G.DEV)
+    ws = torch.empty(L.load().vk_rpn_workspace_bytes(N, Hf * Wf * A, pre), dtype=torch.uint8, device=G.DEV)
+    L.call("vk_rpn_proposals", G.P(lg), A, G.P(dl), 4 * A, N, Hf, Wf, A, G.P(ca), 16, 0.0, G.P(hw),
+           (C.c_float * 4)(1.0, 1.0, 1.0, 1.0), float(min_size), float(thr), pre, post, G.P(ob), G.P(ol), G.P(oc),
+           G.P(flag), G.P(ws), ws.numel(), G.stream())
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    cnt = oc.cpu().tolist()
+    return [(ob[i, :cnt[i]].cpu(), ol[i, :cnt[i]].cpu()) for i in range(N)]
+
+
+def test_rpn_proposals_golden(kat):
+    """Same RPN head outputs in -> the reference's proposals out (golden from the reference module)."""
+    res = _rpn_gpu(torch.from_numpy(kat["rpn/objectness"]), torch.from_numpy(kat["rpn/deltas"]),
+                   kat["rpn/shapes"].tolist(), kat["anchors/cell"], pre=400, post=40, thr=0.7)
+    for i, (b, l) in enumerate(res):
+        assert b.shape == kat[f"rpn/boxes_{i}"].shape          # same number of survivors
+        np.testing.assert_array_equal(l.numpy(), kat[f"rpn/logits_{i}"])   # same anchors, same order
+        assert G.rel_err(b, kat[f"rpn/boxes_{i}"]) <= 2e-6
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_rpn_proposals_full_size(ties):
+    """50x84x15 = 63 000 anchors, top 6000, NMS 0.7, keep 300: kept set identical to the oracle."""
+    g = _rng(99 + ties)
+    N, A, Hf, Wf = 2, 15, 50, 84
+    obj = torch.from_numpy(g.standard_normal((N, A, Hf, Wf)).astype(np.float32) * 3)
+    if ties:
+        obj = torch.round(obj * 8) / 8
+    dlt = torch.from_numpy(g.standard_normal((N, 4 * A, Hf, Wf)).astype(np.float32) * 0.3)
+    shapes = [[800, 1333], [750, 1200]]
+    from vltk_amd.weights import cell_anchors
+    cell = cell_anchors([32, 64, 128, 256, 512], [0.5, 1.0, 2.0])
+    d = vg_c4_config_dict()
+    d["proposal_generator"]["min_size"] = 2
+    o = FRCNNOracle(Config(d), {"proposal_generator.anchor_generator.cell_anchors.0": torch.from_numpy(cell)})
+    ref = o.rpn_proposals(obj, dlt, shapes)
+    got = _rpn_gpu(obj, dlt, shapes, cell, pre=6000, post=300, thr=0.7, min_size=2.0)
+    for (rb, rl), (gb, gl) in zip(ref, got):
+        assert len(gb) == len(rb) == 300
+        np.testing.assert_array_equal(gl.numpy(), rl.numpy())
+        assert G.rel_err(gb, rb) <= 2e-6
+
+
+@pytest.mark.parametrize("tag", ["roiout", "roiout_scaled"])
+def test_roi_outputs_golden(kat, tag):
+    """ROIOutputs.inference incl. do_nms' threshold-list retry, against the reference's own outputs."""
+    N, R, Cn, An, Fd = 2, 20, 10, 5, 16
+    counts = [20, 17]
+    props = np.zeros((N, R, 4), np.float32)
+    K = N * R
+
+    def scatter(a):
+        out = np.zeros((K,) + a.shape[1:], np.float32)
+        out[0:20] = a[0:20]
+        out[20:37] = a[20:37]
+        return out
+    for i in range(N):
+        props[i, :counts[i]] = kat[f"roiout/props_{i}"]
+    dev = G.DEV
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    obj, attr = t(scatter(kat["roiout/obj_logits"])), t(scatter(kat["roiout/attr_logits"]))
+    bd, ft = t(scatter(kat["roiout/box_deltas"])), t(scatter(kat["roiout/feats_in"]))
+    pr, cn = t(props), torch.tensor(counts, dtype=torch.int32, device=dev)
+    hw = torch.tensor(kat["roiout/sizes"], dtype=torch.int32, device=dev)
+    sc = t(kat["roiout/scales"].astype(np.float32)) if tag == "roiout_scaled" else None
+    rp = L.vk_roi_params()
+    thr = kat["roiout/nms_thresh"].tolist()
+    rp.num_nms_thresh = len(thr)
+    for i, v in enumerate(thr):
+        rp.nms_thresh[i] = v
+    rp.min_detections, rp.max_detections = 6, 8
+    D = 8
+    bufs = dict(obj_ids=torch.zeros((N, D), dtype=torch.int64, device=dev), obj_probs=torch.zeros((N, D), device=dev),
+                attr_ids=torch.zeros((N, D), dtype=torch.int64, device=dev), attr_probs=torch.zeros((N, D), device=dev),
+                boxes=torch.zeros((N, D, 4), device=dev), preds_per_image=torch.zeros((N,), dtype=torch.int64, device=dev),
+                roi_features=torch.zeros((N, D, Fd), device=dev))
+    out = L.vk_outputs(*[bufs[k].data_ptr() for k in ("obj_ids", "obj_probs", "attr_ids", "attr_probs", "boxes",
+                                                      "preds_per_image", "roi_features")])
+    keep = torch.zeros((N, D), dtype=torch.int64, device=dev)
+    flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    L.call("vk_roi_outputs", G.P(obj), Cn + 1, G.P(attr), An + 1, G.P(bd), 4 * Cn, 0, G.P(pr), G.P(cn), G.P(ft), Fd,
+           N, R, Cn, An, G.P(hw), G.P(sc), (C.c_float * 4)(10.0, 10.0, 5.0, 5.0), C.byref(rp), C.byref(out),
+           G.P(keep), G.P(flag), G.stream())
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    ppi = bufs["preds_per_image"].cpu().tolist()
+    for i in range(N):
+        n = len(kat[f"{tag}/classes_{i}"])
+        assert ppi[i] == n
+        np.testing.assert_array_equal(bufs["obj_ids"][i, :n].cpu().numpy(), kat[f"{tag}/classes_{i}"])
+        np.testing.assert_array_equal(bufs["attr_ids"][i, :n].cpu().numpy(), kat[f"{tag}/attrs_{i}"])
+        np.testing.assert_array_equal(bufs["roi_features"][i, :n].cpu().numpy(), kat[f"{tag}/feats_{i}"])
+        assert G.rel_err(bufs["obj_probs"][i, :n].cpu(), kat[f"{tag}/probs_{i}"]) <= 2e-6
+        assert G.rel_err(bufs["attr_probs"][i, :n].cpu(), kat[f"{tag}/attr_probs_{i}"]) <= 2e-6
+        assert G.rel_err(bufs["boxes"][i, :n].cpu(), kat[f"{tag}/boxes_{i}"]) <= 2e-6
+        assert (bufs["roi_features"][i, n:] == 0).all() and (bufs["boxes"][i, n:] == 0).all()

@@ -1,0 +1,980 @@
+// Model handle, weight loading / BN folding / repacking, workspace arena and the forward
+// pass orchestration of libvltk_hip.so.
+//
+// Replaces (reference vltk/modeling/frcnn.py): FRCNN.__init__ :1744-1755, build_backbone
+// :200-261, Res5ROIHeads.__init__ :1312-1363, the local branch of from_pretrained's
+// load_state_dict :1862-1881, and FRCNN.inference :1942-2004 (call order of backbone ->
+// proposal generator -> roi heads -> roi outputs).
+//
+// Data layout in HBM: every activation is NHWC in the handle's precision; one arena
+// (single hipMalloc, re-grown only when a larger problem arrives) holds all intermediates
+// so the steady state allocates nothing.  The Res5 head runs over RoI *chunks* so that the
+// chunk's intermediates (pooled 14x14x1024 -> ... -> 14x14x2048) stay resident in the
+// 256 MiB Infinity Cache between consecutive convolutions instead of round-tripping HBM.
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vk_common.h"
+
+namespace vk {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+};
+
+struct ConvLayer {
+    std::string prefix;
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0, dil = 1;
+    bool bn = true, relu = false;
+    void *w = nullptr;       // device, packed
+    float *b = nullptr;      // device, [packed_cout]
+};
+
+struct Block {
+    ConvLayer conv1, conv2, conv3, shortcut;
+    bool has_shortcut = false;
+};
+
+static const int kBlocks[3][4] = {{3, 4, 6, 3}, {3, 4, 23, 3}, {3, 8, 36, 3}};   // frcnn.py:226
+
+}  // namespace vk
+
+using namespace vk;
+
+struct vk_handle {
+    vk_config cfg;
+    int device = 0;
+    vk_dtype dt = VK_F16;
+    bool finalized = false;
+    std::vector<std::string> names;                 // expected state-dict tensors (strict load)
+    std::map<std::string, HostTensor> host;
+
+    ConvLayer stem;
+    std::vector<Block> stages[3];                   // res2, res3, res4
+    std::vector<Block> res5;
+    ConvLayer rpn_conv, rpn_heads;                  // rpn_heads = [objectness | anchor_deltas] fused 1x1
+    ConvLayer cls_score, fc_attr, attr_score;       // plain GEMMs (1x1 "convs" over K RoIs)
+    void *bbox_w = nullptr;                         // [4C][F] in dt, unpadded rows (gathered per RoI)
+    float *bbox_b = nullptr;
+    void *emb = nullptr;                            // [C+1][F/8] in dt
+    float *cell_anchors = nullptr;                  // [A][4]
+    int A = 0, res4_c = 0, res5_c = 0, hid = 0, emb_dim = 0;
+    std::vector<void *> owned;                      // device allocations to free
+
+    // arena
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    int head_chunk = 64;                            // RoIs per Res5 chunk (vk_set_option "head_chunk")
+
+    // stage bookkeeping of the last forward
+    struct Stage {
+        const void *ptr;
+        vk_dtype dt;
+        int64_t shape[4];
+        int ndim;
+    };
+    std::map<std::string, Stage> stages_out;
+    bool timing = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace vk {
+
+static void add_conv_names(std::vector<std::string> &n, const std::string &p, bool bn) {
+    n.push_back(p + ".weight");
+    if (bn) {
+        n.push_back(p + ".norm.weight");
+        n.push_back(p + ".norm.bias");
+        n.push_back(p + ".norm.running_mean");
+        n.push_back(p + ".norm.running_var");
+    } else {
+        n.push_back(p + ".bias");
+    }
+}
+
+static Block make_block(const std::string &p, int cin, int cmid, int cout, int stride, int dil, bool stride_in_1x1,
+                        std::vector<std::string> &names) {
+    Block b;
+    const int s1 = stride_in_1x1 ? stride : 1, s3 = stride_in_1x1 ? 1 : stride;   // frcnn.py:932
+    b.has_shortcut = cin != cout;
+    if (b.has_shortcut) {
+        b.shortcut = ConvLayer{p + ".shortcut", cin, cout, 1, stride, 0, 1, true, false};
+        add_conv_names(names, b.shortcut.prefix, true);
+    }
+    b.conv1 = ConvLayer{p + ".conv1", cin, cmid, 1, s1, 0, 1, true, true};
+    b.conv2 = ConvLayer{p + ".conv2", cmid, cmid, 3, s3, dil, dil, true, true};
+    b.conv3 = ConvLayer{p + ".conv3", cmid, cout, 1, 1, 0, 1, true, true};   // relu after the residual add
+    add_conv_names(names, b.conv1.prefix, true);
+    add_conv_names(names, b.conv2.prefix, true);
+    add_conv_names(names, b.conv3.prefix, true);
+    return b;
+}
+
+static int dev_alloc(vk_handle *h, size_t bytes, void **out) {
+    void *p = nullptr;
+    VK_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    h->owned.push_back(p);
+    *out = p;
+    return VK_OK;
+}
+
+static int upload(vk_handle *h, const void *host, size_t bytes, void **out) {
+    VK_TRY(dev_alloc(h, bytes, out));
+    VK_CHECK_HIP(hipMemcpy(*out, host, bytes, hipMemcpyHostToDevice));
+    return VK_OK;
+}
+
+static const HostTensor *get_t(vk_handle *h, const std::string &name, std::vector<int64_t> shape) {
+    auto it = h->host.find(name);
+    if (it == h->host.end() || !it->second.loaded) {
+        set_error("missing weight '%s' (strict load)", name.c_str());
+        return nullptr;
+    }
+    if (it->second.shape != shape) {
+        std::string got, want;
+        for (auto v : it->second.shape) got += std::to_string(v) + ",";
+        for (auto v : shape) want += std::to_string(v) + ",";
+        set_error("weight '%s' has shape [%s], expected [%s]", name.c_str(), got.c_str(), want.c_str());
+        return nullptr;
+    }
+    return &it->second;
+}
+
+static int finalize_conv(vk_handle *h, ConvLayer &L) {
+    const HostTensor *w = get_t(h, L.prefix + ".weight", {L.cout, L.cin, L.k, L.k});
+    if (!w) return VK_EWEIGHTS;
+    std::vector<float> bn;
+    const float *bnp = nullptr, *bias = nullptr;
+    if (L.bn) {
+        const char *parts[4] = {".norm.weight", ".norm.bias", ".norm.running_mean", ".norm.running_var"};
+        bn.resize(4 * (size_t)L.cout);
+        for (int i = 0; i < 4; ++i) {
+            const HostTensor *t = get_t(h, L.prefix + parts[i], {L.cout});
+            if (!t) return VK_EWEIGHTS;
+            memcpy(bn.data() + (size_t)i * L.cout, t->data.data(), sizeof(float) * L.cout);
+        }
+        bnp = bn.data();
+    } else {
+        const HostTensor *t = get_t(h, L.prefix + ".bias", {L.cout});
+        if (!t) return VK_EWEIGHTS;
+        bias = t->data.data();
+    }
+    const size_t wb = vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, h->dt);
+    std::vector<char> packed(wb);
+    std::vector<float> pb(vk_packed_cout(L.cout));
+    VK_TRY(vk_pack_conv_weight(w->data.data(), bnp, bias, L.cout, L.cin, L.k, L.k, h->dt, packed.data(), pb.data()));
+    VK_TRY(upload(h, packed.data(), wb, &L.w));
+    VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&L.b));
+    return VK_OK;
+}
+
+static int finalize_block(vk_handle *h, Block &b) {
+    if (b.has_shortcut) VK_TRY(finalize_conv(h, b.shortcut));
+    VK_TRY(finalize_conv(h, b.conv1));
+    VK_TRY(finalize_conv(h, b.conv2));
+    VK_TRY(finalize_conv(h, b.conv3));
+    return VK_OK;
+}
+
+static void to_dt(const float *src, size_t n, vk_dtype dt, void *dst) {
+    if (dt == VK_F16) {
+        _Float16 *d = (_Float16 *)dst;
+        for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];
+    } else {
+        memcpy(dst, src, n * sizeof(float));
+    }
+}
+
+// ---- arena ----
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(char *b) : base(b) {}
+    void *take(size_t bytes) {
+        void *p = base ? base + off : nullptr;
+        off += align_up(bytes ? bytes : 16, 256);
+        return p;
+    }
+};
+
+struct Plan {
+    // geometry
+    int N, H, W, Hp, Wp, H1, W1, Hs[3], Ws[3], Hf, Wf, R, K, P, chunk;
+    // buffers
+    void *img_pad, *stem_out, *bufA, *bufB, *bufSC, *bufT1, *bufT2;
+    void *rpn_hid;
+    float *rpn_out, *prop_boxes, *prop_logits, *rois;
+    int32_t *prop_counts, *image_hw, *nonfinite;
+    float *scales;
+    void *rpn_ws;
+    size_t rpn_ws_bytes;
+    void *pooled, *h_t1, *h_t2, *h_a, *h_b, *h_sc;
+    float *feat;
+    void *featT, *concat, *attr_hid;
+    float *cls_logits, *attr_logits, *obj_prob, *attr_prob, *chosen;
+    int32_t *obj_cls, *attr_cls, *max_class;
+    int64_t *keep_ids;
+    size_t total;
+};
+
+static void conv_out_hw(int H, int W, int k, int s, int p, int d, int *Ho, int *Wo) {
+    *Ho = (H + 2 * p - (d * (k - 1) + 1)) / s + 1;
+    *Wo = (W + 2 * p - (d * (k - 1) + 1)) / s + 1;
+}
+
+static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
+    Plan p;
+    memset(&p, 0, sizeof(p));
+    const vk_config &c = h->cfg;
+    const size_t es = dtype_size(h->dt);
+    p.N = N;
+    p.H = H;
+    p.W = W;
+    conv_out_hw(H, W, 7, 2, 3, 1, &p.H1, &p.W1);
+    p.Hp = std::max(H + 6, 2 * p.H1 + 6);
+    p.Wp = std::max(W + 6, 2 * p.W1 + 6);
+    p.Wp = (p.Wp + 1) & ~1;
+    int h2, w2;
+    vk_stem_out_hw(H, W, c.caffe_maxpool, &h2, &w2);
+    p.Hs[0] = h2;
+    p.Ws[0] = w2;
+    for (int s = 1; s < 3; ++s) conv_out_hw(p.Hs[s - 1], p.Ws[s - 1], 1, 2, 0, 1, &p.Hs[s], &p.Ws[s]);
+    p.Hf = p.Hs[2];
+    p.Wf = p.Ws[2];
+    p.R = c.post_nms_topk;
+    p.K = N * p.R;
+    p.P = c.pooler_resolution;
+    p.chunk = std::min(h->head_chunk > 0 ? h->head_chunk : p.K, p.K);
+
+    Carver cv(base);
+    p.img_pad = cv.take((size_t)N * p.Hp * p.Wp * 4 * es);
+    p.stem_out = cv.take((size_t)N * p.H1 * p.W1 * c.stem_out_channels * es);
+    size_t max_out = 0, max_mid = 0;
+    int cout = c.res2_out_channels, cmid = c.num_groups * c.width_per_group;
+    for (int s = 0; s < 3; ++s) {
+        const size_t px_out = (size_t)N * p.Hs[s] * p.Ws[s];
+        const size_t px_in = s == 0 ? px_out : (size_t)N * p.Hs[s - 1] * p.Ws[s - 1];
+        max_out = std::max(max_out, px_out * cout * es);
+        max_mid = std::max(max_mid, (c.stride_in_1x1 ? px_out : px_in) * cmid * es);
+        cout *= 2;
+        cmid *= 2;
+    }
+    p.bufA = cv.take(max_out);
+    p.bufB = cv.take(max_out);
+    p.bufSC = cv.take(max_out);
+    p.bufT1 = cv.take(max_mid);
+    p.bufT2 = cv.take(max_mid);
+    const size_t Mf = (size_t)N * p.Hf * p.Wf;
+    p.rpn_hid = cv.take(Mf * h->hid * es);
+    p.rpn_out = (float *)cv.take(Mf * (size_t)((5 * h->A + 7) / 8 * 8) * sizeof(float));
+    p.prop_boxes = (float *)cv.take((size_t)p.K * 4 * sizeof(float));
+    p.prop_logits = (float *)cv.take((size_t)p.K * sizeof(float));
+    p.rois = (float *)cv.take((size_t)p.K * 5 * sizeof(float));
+    p.prop_counts = (int32_t *)cv.take((size_t)N * sizeof(int32_t));
+    p.image_hw = (int32_t *)cv.take((size_t)N * 2 * sizeof(int32_t));
+    p.scales = (float *)cv.take((size_t)N * 2 * sizeof(float));
+    p.nonfinite = (int32_t *)cv.take(sizeof(int32_t));
+    p.rpn_ws_bytes = vk_rpn_workspace_bytes(N, p.Hf * p.Wf * h->A, c.pre_nms_topk);
+    p.rpn_ws = cv.take(p.rpn_ws_bytes);
+    const size_t rows = (size_t)p.chunk * p.P * p.P;
+    const int mid5 = c.num_groups * c.width_per_group * 8;
+    p.pooled = cv.take(rows * h->res4_c * es);
+    p.h_t1 = cv.take(rows * mid5 * es);
+    p.h_t2 = cv.take(rows * mid5 * es);
+    p.h_a = cv.take(rows * h->res5_c * es);
+    p.h_b = cv.take(rows * h->res5_c * es);
+    p.h_sc = cv.take(rows * h->res5_c * es);
+    p.feat = (float *)cv.take((size_t)p.K * h->res5_c * sizeof(float));
+    p.featT = cv.take((size_t)p.K * h->res5_c * es);
+    p.concat = cv.take((size_t)p.K * (h->res5_c + h->emb_dim) * es);
+    p.attr_hid = cv.take((size_t)p.K * (h->res5_c / 4) * es);
+    p.cls_logits = (float *)cv.take((size_t)p.K * ((c.num_classes + 1 + 7) / 8 * 8) * sizeof(float));
+    p.attr_logits = (float *)cv.take((size_t)p.K * ((c.num_attrs + 1 + 7) / 8 * 8) * sizeof(float));
+    p.obj_prob = (float *)cv.take((size_t)p.K * sizeof(float));
+    p.attr_prob = (float *)cv.take((size_t)p.K * sizeof(float));
+    p.chosen = (float *)cv.take((size_t)p.K * 4 * sizeof(float));
+    p.obj_cls = (int32_t *)cv.take((size_t)p.K * sizeof(int32_t));
+    p.attr_cls = (int32_t *)cv.take((size_t)p.K * sizeof(int32_t));
+    p.max_class = (int32_t *)cv.take((size_t)p.K * sizeof(int32_t));
+    p.keep_ids = (int64_t *)cv.take((size_t)N * D * sizeof(int64_t));
+    p.total = cv.off;
+    return p;
+}
+
+static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int H, int W, const void *res, void *y,
+                    bool relu, vk_dtype out_dt, int ldy, hipStream_t s, int *Ho = nullptr, int *Wo = nullptr) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = L.w;
+    a.bias = L.b;
+    a.res = res;
+    a.y = y;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cin = L.cin;
+    conv_out_hw(H, W, L.k, L.stride, L.pad, L.dil, &a.Ho, &a.Wo);
+    a.Cout = L.cout;
+    a.ldy = ldy > 0 ? ldy : (L.cout + 7) / 8 * 8;
+    a.kh = a.kw = L.k;
+    a.stride = L.stride;
+    a.pad = L.pad;
+    a.dil = L.dil;
+    a.relu = relu;
+    a.stem = 0;
+    a.dt = h->dt;
+    a.out_dt = out_dt;
+    if (Ho) *Ho = a.Ho;
+    if (Wo) *Wo = a.Wo;
+    return launch_conv(a, s);
+}
+
+// BottleneckBlock.forward frcnn.py:963-979.  x [N,H,W,cin] -> y [N,Ho,Wo,cout]
+static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, int W, void *t1, void *t2, void *sc,
+                     void *y, hipStream_t s, int *Ho, int *Wo) {
+    int h1, w1, h2, w2;
+    const void *res = x;
+    if (b.has_shortcut) {
+        VK_TRY(run_conv(h, b.shortcut, x, N, H, W, nullptr, sc, false, h->dt, 0, s));
+        res = sc;
+    }
+    VK_TRY(run_conv(h, b.conv1, x, N, H, W, nullptr, t1, true, h->dt, 0, s, &h1, &w1));
+    VK_TRY(run_conv(h, b.conv2, t1, N, h1, w1, nullptr, t2, true, h->dt, 0, s, &h2, &w2));
+    VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo));
+    return VK_OK;
+}
+
+static void set_stage(vk_handle *h, const char *name, const void *ptr, vk_dtype dt, std::initializer_list<int64_t> shape) {
+    vk_handle::Stage st;
+    st.ptr = ptr;
+    st.dt = dt;
+    st.ndim = 0;
+    for (auto v : shape) st.shape[st.ndim++] = v;
+    h->stages_out[name] = st;
+}
+
+}  // namespace vk
+
+extern "C" {
+
+const char *vk_last_error(void) { return g_err; }
+int vk_version(void) { return 1; }
+
+int vk_packed_cout(int cout) { return (cout + CONV_COUT_ALIGN - 1) / CONV_COUT_ALIGN * CONV_COUT_ALIGN; }
+
+size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, vk_dtype dt) {
+    return (size_t)vk_packed_cout(cout) * kh * kw * cin * dtype_size(dt);
+}
+
+int vk_pack_conv_weight(const float *w, const float *bn, const float *bias, int cout, int cin, int kh, int kw, vk_dtype dt,
+                        void *w_packed, float *bias_packed) {
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "pack: dtype must be f16 or f32");
+    VK_REQUIRE((cin * (int)dtype_size(dt)) % CONV_KTILE_BYTES == 0, VK_EINVAL,
+               "pack: cin=%d is not a whole number of 128-byte K-tiles for this dtype", cin);
+    const int cp = vk_packed_cout(cout);
+    const size_t K = (size_t)kh * kw * cin;
+    std::vector<float> row(K);
+    for (int co = 0; co < cp; ++co) {
+        double s = 1.0;
+        float b = 0.f;
+        if (co < cout) {
+            if (bn) {   // eval BatchNorm folded into the conv: eps 1e-5 (nn.BatchNorm2d default)
+                const double g = bn[co], be = bn[cout + co], mu = bn[2 * (size_t)cout + co], var = bn[3 * (size_t)cout + co];
+                s = g / std::sqrt(var + 1e-5);
+                b = (float)(be - mu * s);
+            } else if (bias) {
+                b = bias[co];
+            }
+            for (int c = 0; c < cin; ++c)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        row[((size_t)y * kw + x) * cin + c] = (float)((double)w[(((size_t)co * cin + c) * kh + y) * kw + x] * s);
+        } else {
+            std::fill(row.begin(), row.end(), 0.f);
+        }
+        bias_packed[co] = b;
+        to_dt(row.data(), K, dt, (char *)w_packed + (size_t)co * K * dtype_size(dt));
+    }
+    return VK_OK;
+}
+
+size_t vk_packed_stem_bytes(int cout, vk_dtype dt) {
+    const int ktiles = dt == VK_F16 ? 4 : 7;
+    return (size_t)vk_packed_cout(cout) * ktiles * CONV_KTILE_BYTES;
+}
+
+int vk_pack_stem_weight(const float *w, const float *bn, int cout, vk_dtype dt, void *w_packed, float *bias_packed) {
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "pack_stem: dtype must be f16 or f32");
+    const int cp = vk_packed_cout(cout);
+    const int ktiles = dt == VK_F16 ? 4 : 7;
+    const size_t K = (size_t)ktiles * CONV_KTILE_BYTES / dtype_size(dt);   // 256 (f16) / 224 (f32)
+    std::vector<float> row(K);
+    for (int co = 0; co < cp; ++co) {
+        std::fill(row.begin(), row.end(), 0.f);
+        float b = 0.f;
+        if (co < cout) {
+            double s = 1.0;
+            if (bn) {
+                const double g = bn[co], be = bn[cout + co], mu = bn[2 * (size_t)cout + co], var = bn[3 * (size_t)cout + co];
+                s = g / std::sqrt(var + 1e-5);
+                b = (float)(be - mu * s);
+            }
+            for (int c = 0; c < 3; ++c)
+                for (int y = 0; y < 7; ++y)
+                    for (int x = 0; x < 7; ++x)   // K index = kernel row * 32 + (kernel col * 4 + channel)
+                        row[(size_t)y * 32 + x * 4 + c] = (float)((double)w[(((size_t)co * 3 + c) * 7 + y) * 7 + x] * s);
+        }
+        bias_packed[co] = b;
+        to_dt(row.data(), K, dt, (char *)w_packed + (size_t)co * K * dtype_size(dt));
+    }
+    return VK_OK;
+}
+
+int vk_conv2d(const void *x, int N, int H, int W, int cin, const void *w_packed, const float *bias_packed,
+              const void *residual, void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil, int relu,
+              vk_dtype dt, vk_dtype out_dt, void *stream) {
+    VK_REQUIRE(kh == kw && kh >= 1 && stride >= 1 && dil >= 1 && pad >= 0, VK_EINVAL, "conv2d: bad geometry");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = w_packed;
+    a.bias = bias_packed;
+    a.res = residual;
+    a.y = y;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cin = cin;
+    conv_out_hw(H, W, kh, stride, pad, dil, &a.Ho, &a.Wo);
+    VK_REQUIRE(a.Ho > 0 && a.Wo > 0 && N > 0, VK_EINVAL, "conv2d: empty output");
+    a.Cout = cout;
+    a.ldy = ldy;
+    a.kh = kh;
+    a.kw = kw;
+    a.stride = stride;
+    a.pad = pad;
+    a.dil = dil;
+    a.relu = relu;
+    a.dt = dt;
+    a.out_dt = out_dt;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+static void stem_geom(int H, int W, int *H1, int *W1, int *Hp, int *Wp) {
+    conv_out_hw(H, W, 7, 2, 3, 1, H1, W1);
+    *Hp = std::max(H + 6, 2 * *H1 + 6);
+    *Wp = (std::max(W + 6, 2 * *W1 + 6) + 1) & ~1;
+}
+
+size_t vk_stem_workspace_bytes(int N, int H, int W, int cout, vk_dtype dt) {
+    int H1, W1, Hp, Wp;
+    stem_geom(H, W, &H1, &W1, &Hp, &Wp);
+    return align_up((size_t)N * Hp * Wp * 4 * dtype_size(dt), 256) + align_up((size_t)N * H1 * W1 * cout * dtype_size(dt), 256);
+}
+
+static int stem_impl(const float *x, int N, int H, int W, const void *w, const float *b, int cout, int caffe, void *y,
+                     vk_dtype dt, void *img_pad, void *stem_out, hipStream_t s) {
+    int H1, W1, Hp, Wp;
+    stem_geom(H, W, &H1, &W1, &Hp, &Wp);
+    VK_TRY(launch_stem_pack(x, img_pad, N, H, W, Hp, Wp, dt, s));
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = img_pad;
+    a.w = w;
+    a.bias = b;
+    a.y = stem_out;
+    a.N = N;
+    a.H = Hp;
+    a.W = Wp;
+    a.Cin = 4;
+    a.Ho = H1;
+    a.Wo = W1;
+    a.Cout = cout;
+    a.ldy = (cout + 7) / 8 * 8;
+    a.kh = a.kw = 7;
+    a.stride = 2;
+    a.pad = 0;
+    a.dil = 1;
+    a.relu = 1;
+    a.stem = 1;
+    a.dt = a.out_dt = dt;
+    VK_TRY(launch_conv(a, s));
+    return launch_maxpool(stem_out, y, N, H1, W1, cout, caffe, dt, s);
+}
+
+int vk_stem(const float *x, int N, int H, int W, const void *w_packed, const float *bias_packed, int cout,
+            int caffe_maxpool, void *y, vk_dtype dt, void *workspace, size_t workspace_bytes, void *stream) {
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "stem: bad dtype");
+    VK_REQUIRE(cout % 8 == 0, VK_EINVAL, "stem: cout must be a multiple of 8");
+    VK_REQUIRE(H >= 16 && W >= 16, VK_EINVAL, "stem: image %dx%d too small", H, W);
+    VK_REQUIRE(workspace && workspace_bytes >= vk_stem_workspace_bytes(N, H, W, cout, dt), VK_EINVAL, "stem: workspace too small");
+    int H1, W1, Hp, Wp;
+    stem_geom(H, W, &H1, &W1, &Hp, &Wp);
+    char *img_pad = (char *)workspace;
+    char *stem_out = img_pad + align_up((size_t)N * Hp * Wp * 4 * dtype_size(dt), 256);
+    return stem_impl(x, N, H, W, w_packed, bias_packed, cout, caffe_maxpool, y, dt, img_pad, stem_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+int vk_create(const vk_config *cfg, int device, vk_handle **out) {
+    VK_REQUIRE(cfg && out, VK_EINVAL, "create: null argument");
+    VK_REQUIRE(cfg->depth == 50 || cfg->depth == 101 || cfg->depth == 152, VK_EINVAL, "create: depth %d unsupported", cfg->depth);
+    VK_REQUIRE(cfg->num_groups == 1, VK_EINVAL, "create: grouped 3x3 convolutions (NUM_GROUPS=%d) are not built yet", cfg->num_groups);
+    VK_REQUIRE(cfg->res5_halve == 0, VK_EINVAL, "create: RES5HALVE=true is not supported");
+    VK_REQUIRE(cfg->stride_in_1x1 != 0, VK_EINVAL,
+               "create: STRIDE_IN_1X1=false leaves a stride-2 conv2 in res5 (frcnn.py:1351-1355) -- not supported");
+    VK_REQUIRE(cfg->precision == VK_F16 || cfg->precision == VK_F32, VK_EINVAL, "create: precision must be VK_F16 or VK_F32");
+    VK_REQUIRE(cfg->num_sizes >= 1 && cfg->num_sizes <= VK_MAX_ANCHOR_DIM && cfg->num_ratios >= 1 &&
+                   cfg->num_ratios <= VK_MAX_ANCHOR_DIM, VK_EINVAL, "create: bad anchor configuration");
+    VK_REQUIRE(cfg->pre_nms_topk >= 1 && cfg->pre_nms_topk <= 8192, VK_EINVAL, "create: PRE_NMS_TOPK_TEST must be in 1..8192");
+    VK_REQUIRE(cfg->post_nms_topk >= 1 && cfg->post_nms_topk <= 1024 && cfg->post_nms_topk <= cfg->pre_nms_topk, VK_EINVAL,
+               "create: POST_NMS_TOPK_TEST must be in 1..min(1024, PRE_NMS_TOPK_TEST)");
+    VK_REQUIRE(cfg->use_attr != 0, VK_EINVAL, "create: ROI_BOX_HEAD.ATTR=false is not supported");
+    VK_REQUIRE(cfg->stem_out_channels == 64, VK_EINVAL, "create: STEM_OUT_CHANNELS must be 64");
+    VK_CHECK_HIP(hipSetDevice(device));
+    vk_handle *h = new vk_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    h->dt = (vk_dtype)cfg->precision;
+    const char *env = getenv("VK_HEAD_CHUNK");
+    if (env && atoi(env) > 0) h->head_chunk = atoi(env);
+    const int di = cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2);
+    add_conv_names(h->names, "backbone.stem.conv1", true);
+    h->stem = ConvLayer{"backbone.stem.conv1", 3, cfg->stem_out_channels, 7, 2, 3, 1, true, true};
+    int cin = cfg->stem_out_channels, cout = cfg->res2_out_channels, cmid = cfg->num_groups * cfg->width_per_group;
+    const char *sn[3] = {"res2", "res3", "res4"};
+    for (int s = 0; s < 3; ++s) {
+        for (int b = 0; b < kBlocks[di][s]; ++b) {
+            const int stride = (b == 0 && s > 0) ? 2 : 1;   // frcnn.py:237
+            h->stages[s].push_back(make_block(std::string("backbone.") + sn[s] + "." + std::to_string(b), cin, cmid, cout,
+                                              stride, 1, cfg->stride_in_1x1 != 0, h->names));
+            cin = cout;
+        }
+        cout *= 2;
+        cmid *= 2;
+    }
+    h->res4_c = cin;
+    h->A = cfg->num_sizes * cfg->num_ratios;
+    h->names.push_back("proposal_generator.anchor_generator.cell_anchors.0");
+    h->hid = cfg->rpn_hidden_channels == -1 ? h->res4_c : cfg->rpn_hidden_channels;
+    h->rpn_conv = ConvLayer{"proposal_generator.rpn_head.conv", h->res4_c, h->hid, 3, 1, 1, 1, false, true};
+    add_conv_names(h->names, h->rpn_conv.prefix, false);
+    add_conv_names(h->names, "proposal_generator.rpn_head.objectness_logits", false);
+    add_conv_names(h->names, "proposal_generator.rpn_head.anchor_deltas", false);
+    h->rpn_heads = ConvLayer{"proposal_generator.rpn_head.(objectness_logits|anchor_deltas)", h->hid, 5 * h->A, 1, 1, 0, 1, false, false};
+    h->res5_c = cfg->res2_out_channels * 8;
+    const int mid5 = cfg->num_groups * cfg->width_per_group * 8;
+    cin = h->res4_c;
+    for (int b = 0; b < 3; ++b) {   // VG res5: stride 1, conv2 dilation/padding 2 (frcnn.py:1345-1355)
+        h->res5.push_back(make_block("roi_heads.res5." + std::to_string(b), cin, mid5, h->res5_c, 1, 2, true, h->names));
+        cin = h->res5_c;
+    }
+    const int C = cfg->num_classes, F = h->res5_c;
+    h->emb_dim = F / 8;
+    const std::string bp = "roi_heads.box_predictor.";
+    h->cls_score = ConvLayer{bp + "cls_score", F, C + 1, 1, 1, 0, 1, false, false};
+    h->fc_attr = ConvLayer{bp + "fc_attr", F + h->emb_dim, F / 4, 1, 1, 0, 1, false, true};
+    h->attr_score = ConvLayer{bp + "attr_score", F / 4, cfg->num_attrs + 1, 1, 1, 0, 1, false, false};
+    for (const char *n : {"cls_score", "bbox_pred"}) add_conv_names(h->names, bp + n, false);
+    h->names.push_back(bp + "cls_embedding.weight");
+    for (const char *n : {"fc_attr", "attr_score"}) add_conv_names(h->names, bp + n, false);
+    *out = h;
+    return VK_OK;
+}
+
+int vk_num_weights(vk_handle *h, int *count) {
+    VK_REQUIRE(h && count, VK_EINVAL, "null argument");
+    *count = (int)h->names.size();
+    return VK_OK;
+}
+
+int vk_weight_name(vk_handle *h, int index, const char **name) {
+    VK_REQUIRE(h && name && index >= 0 && index < (int)h->names.size(), VK_EINVAL, "weight index out of range");
+    *name = h->names[index].c_str();
+    return VK_OK;
+}
+
+int vk_load_weights(vk_handle *h, const char *name, const void *host_ptr, const int64_t *shape, int ndim, vk_dtype dtype) {
+    VK_REQUIRE(h && name && host_ptr && (shape || ndim == 0), VK_EINVAL, "load_weights: null argument");
+    VK_REQUIRE(!h->finalized, VK_EINVAL, "load_weights: model already finalized");
+    std::string key(name);
+    // old -> new naming, as the reference's loader does (frcnn.py:1862-1872)
+    size_t pos;
+    if ((pos = key.find("gamma")) != std::string::npos) key.replace(pos, 5, "weight");
+    if ((pos = key.find("beta")) != std::string::npos) key.replace(pos, 4, "bias");
+    if (key.size() > 19 && key.compare(key.size() - 19, 19, "num_batches_tracked") == 0) return VK_OK;   // unused in eval
+    bool known = false;
+    for (auto &n : h->names) known |= (n == key);
+    VK_REQUIRE(known, VK_EWEIGHTS, "unexpected key '%s' in state_dict (strict load)", key.c_str());
+    VK_REQUIRE(dtype == VK_F32, VK_EINVAL, "load_weights: '%s' must be float32", key.c_str());
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign((const float *)host_ptr, (const float *)host_ptr + n);
+    t.loaded = true;
+    h->host[key] = std::move(t);
+    return VK_OK;
+}
+
+int vk_finalize(vk_handle *h) {
+    VK_REQUIRE(h, VK_EINVAL, "finalize: null handle");
+    VK_REQUIRE(!h->finalized, VK_EINVAL, "finalize: already finalized");
+    VK_CHECK_HIP(hipSetDevice(h->device));
+    for (auto &n : h->names) {
+        auto it = h->host.find(n);
+        VK_REQUIRE(it != h->host.end() && it->second.loaded, VK_EWEIGHTS, "missing key '%s' in state_dict (strict load)", n.c_str());
+    }
+    const vk_config &c = h->cfg;
+    // stem
+    {
+        const HostTensor *w = get_t(h, "backbone.stem.conv1.weight", {c.stem_out_channels, 3, 7, 7});
+        if (!w) return VK_EWEIGHTS;
+        std::vector<float> bn(4 * (size_t)c.stem_out_channels);
+        const char *parts[4] = {".norm.weight", ".norm.bias", ".norm.running_mean", ".norm.running_var"};
+        for (int i = 0; i < 4; ++i) {
+            const HostTensor *t = get_t(h, std::string("backbone.stem.conv1") + parts[i], {c.stem_out_channels});
+            if (!t) return VK_EWEIGHTS;
+            memcpy(bn.data() + (size_t)i * c.stem_out_channels, t->data.data(), sizeof(float) * c.stem_out_channels);
+        }
+        std::vector<char> packed(vk_packed_stem_bytes(c.stem_out_channels, h->dt));
+        std::vector<float> pb(vk_packed_cout(c.stem_out_channels));
+        VK_TRY(vk_pack_stem_weight(w->data.data(), bn.data(), c.stem_out_channels, h->dt, packed.data(), pb.data()));
+        VK_TRY(upload(h, packed.data(), packed.size(), &h->stem.w));
+        VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&h->stem.b));
+    }
+    for (int s = 0; s < 3; ++s)
+        for (auto &b : h->stages[s]) VK_TRY(finalize_block(h, b));
+    for (auto &b : h->res5) VK_TRY(finalize_block(h, b));
+    VK_TRY(finalize_conv(h, h->rpn_conv));
+    {   // fuse the two 1x1 RPN heads into one GEMM: rows [0,A) objectness, [A,5A) anchor deltas
+        const int A = h->A, hid = h->hid;
+        const HostTensor *wo = get_t(h, "proposal_generator.rpn_head.objectness_logits.weight", {A, hid, 1, 1});
+        const HostTensor *bo = get_t(h, "proposal_generator.rpn_head.objectness_logits.bias", {A});
+        const HostTensor *wd = get_t(h, "proposal_generator.rpn_head.anchor_deltas.weight", {4 * A, hid, 1, 1});
+        const HostTensor *bd = get_t(h, "proposal_generator.rpn_head.anchor_deltas.bias", {4 * A});
+        if (!wo || !bo || !wd || !bd) return VK_EWEIGHTS;
+        std::vector<float> w(wo->data), b(bo->data);
+        w.insert(w.end(), wd->data.begin(), wd->data.end());
+        b.insert(b.end(), bd->data.begin(), bd->data.end());
+        std::vector<char> packed(vk_packed_weight_bytes(5 * A, hid, 1, 1, h->dt));
+        std::vector<float> pb(vk_packed_cout(5 * A));
+        VK_TRY(vk_pack_conv_weight(w.data(), nullptr, b.data(), 5 * A, hid, 1, 1, h->dt, packed.data(), pb.data()));
+        VK_TRY(upload(h, packed.data(), packed.size(), &h->rpn_heads.w));
+        VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&h->rpn_heads.b));
+        const HostTensor *ca = get_t(h, "proposal_generator.anchor_generator.cell_anchors.0", {A, 4});
+        if (!ca) return VK_EWEIGHTS;
+        VK_TRY(upload(h, ca->data.data(), ca->data.size() * sizeof(float), (void **)&h->cell_anchors));
+    }
+    // predictor: Linear weights [out,in] are 1x1 convs [out,in,1,1]
+    const std::string bp = "roi_heads.box_predictor.";
+    for (ConvLayer *L : {&h->cls_score, &h->fc_attr, &h->attr_score}) {
+        auto it = h->host.find(L->prefix + ".weight");
+        if (it != h->host.end() && it->second.shape.size() == 2) {
+            it->second.shape.push_back(1);
+            it->second.shape.push_back(1);
+        }
+        VK_TRY(finalize_conv(h, *L));
+    }
+    {
+        const int C = c.num_classes, F = h->res5_c;
+        const int nb = c.cls_agnostic_bbox_reg ? 1 : C;
+        const HostTensor *w = get_t(h, bp + "bbox_pred.weight", {4 * nb, F});
+        const HostTensor *b = get_t(h, bp + "bbox_pred.bias", {4 * nb});
+        const HostTensor *e = get_t(h, bp + "cls_embedding.weight", {C + 1, h->emb_dim});
+        if (!w || !b || !e) return VK_EWEIGHTS;
+        std::vector<char> tmp(w->data.size() * dtype_size(h->dt));
+        to_dt(w->data.data(), w->data.size(), h->dt, tmp.data());
+        VK_TRY(upload(h, tmp.data(), tmp.size(), &h->bbox_w));
+        VK_TRY(upload(h, b->data.data(), b->data.size() * sizeof(float), (void **)&h->bbox_b));
+        tmp.resize(e->data.size() * dtype_size(h->dt));
+        to_dt(e->data.data(), e->data.size(), h->dt, tmp.data());
+        VK_TRY(upload(h, tmp.data(), tmp.size(), &h->emb));
+    }
+    h->host.clear();
+    h->finalized = true;
+    return VK_OK;
+}
+
+int vk_set_option(vk_handle *h, const char *key, int value) {
+    VK_REQUIRE(h && key, VK_EINVAL, "set_option: null argument");
+    if (!strcmp(key, "head_chunk")) {
+        VK_REQUIRE(value >= 0, VK_EINVAL, "head_chunk must be >= 0 (0 = all RoIs at once)");
+        h->head_chunk = value;
+        return VK_OK;
+    }
+    VK_REQUIRE(false, VK_EINVAL, "unknown option '%s'", key);
+}
+
+int vk_destroy(vk_handle *h) {
+    if (!h) return VK_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : h->owned) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete h;
+    return VK_OK;
+}
+
+int vk_enable_stage_timing(vk_handle *h, int enable) {
+    VK_REQUIRE(h, VK_EINVAL, "null handle");
+    h->timing = enable != 0;
+    if (h->timing && !h->ev[0])
+        for (auto &e : h->ev) VK_CHECK_HIP(hipEventCreate(&e));
+    return VK_OK;
+}
+
+int vk_get_stage_timing(vk_handle *h, float *ms6) {
+    VK_REQUIRE(h && ms6, VK_EINVAL, "null argument");
+    VK_REQUIRE(h->timing && h->ev_valid, VK_EINVAL, "stage timing was not recorded");
+    VK_CHECK_HIP(hipEventSynchronize(h->ev[5]));
+    for (int i = 0; i < 5; ++i) VK_CHECK_HIP(hipEventElapsedTime(&ms6[i], h->ev[i], h->ev[i + 1]));
+    VK_CHECK_HIP(hipEventElapsedTime(&ms6[5], h->ev[0], h->ev[5]));
+    return VK_OK;
+}
+
+int vk_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    VK_REQUIRE(dst_dev && src_dev, VK_EINVAL, "memcpy_d2d: null pointer");
+    VK_CHECK_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return VK_OK;
+}
+
+int vk_get_stage(vk_handle *h, const char *name, const void **dev_ptr, vk_dtype *dtype, int64_t *shape, int *ndim) {
+    VK_REQUIRE(h && name && dev_ptr && dtype && shape && ndim, VK_EINVAL, "null argument");
+    auto it = h->stages_out.find(name);
+    VK_REQUIRE(it != h->stages_out.end(), VK_EINVAL, "unknown stage '%s' (or no forward has run)", name);
+    *dev_ptr = it->second.ptr;
+    *dtype = it->second.dt;
+    *ndim = it->second.ndim;
+    for (int i = 0; i < it->second.ndim; ++i) shape[i] = it->second.shape[i];
+    return VK_OK;
+}
+
+int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const int32_t *image_hw,
+               const float *scales_yx, const vk_roi_params *rp, const vk_outputs *out, void *stream) {
+    VK_REQUIRE(h && images_dev && image_hw && rp && out, VK_EINVAL, "forward: null argument");
+    VK_REQUIRE(h->finalized, VK_EINVAL, "forward: vk_finalize has not been called");
+    VK_REQUIRE(N >= 1 && H >= 32 && W >= 32, VK_EINVAL, "forward: bad input size N=%d H=%d W=%d", N, H, W);
+    VK_REQUIRE(rp->num_nms_thresh >= 1 && rp->num_nms_thresh <= VK_MAX_NMS_THRESH, VK_EINVAL, "forward: 1..%d nms thresholds", VK_MAX_NMS_THRESH);
+    VK_REQUIRE(rp->max_detections >= 1 && rp->max_detections <= h->cfg.post_nms_topk, VK_EINVAL,
+               "forward: max_detections=%d must be in 1..POST_NMS_TOPK_TEST", rp->max_detections);
+    for (int n = 0; n < N; ++n)
+        VK_REQUIRE(image_hw[2 * n] >= 1 && image_hw[2 * n] <= H && image_hw[2 * n + 1] >= 1 && image_hw[2 * n + 1] <= W, VK_EINVAL,
+                   "forward: image_shapes[%d]=(%d,%d) outside the %dx%d batch", n, image_hw[2 * n], image_hw[2 * n + 1], H, W);
+    VK_CHECK_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const vk_config &c = h->cfg;
+    const int D = rp->max_detections;
+
+    Plan need = make_plan(h, nullptr, N, H, W, D);
+    if (need.total > h->arena_bytes) {
+        if (h->arena) {
+            VK_CHECK_HIP(hipDeviceSynchronize());
+            VK_CHECK_HIP(hipFree(h->arena));
+            h->arena = nullptr;
+            h->arena_bytes = 0;
+        }
+        VK_CHECK_HIP(hipMalloc((void **)&h->arena, need.total));
+        h->arena_bytes = need.total;
+    }
+    Plan p = make_plan(h, h->arena, N, H, W, D);
+    h->stages_out.clear();
+    const bool tm = h->timing;
+    if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[0], s));
+
+    VK_CHECK_HIP(hipMemcpyAsync(p.image_hw, image_hw, sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, s));
+    if (scales_yx) VK_CHECK_HIP(hipMemcpyAsync(p.scales, scales_yx, sizeof(float) * 2 * N, hipMemcpyHostToDevice, s));
+    VK_CHECK_HIP(hipMemsetAsync(p.nonfinite, 0, sizeof(int32_t), s));
+
+    // ---- backbone (ResNet.forward frcnn.py:1076-1090) ----
+    VK_TRY(stem_impl(images_dev, N, H, W, h->stem.w, h->stem.b, c.stem_out_channels, c.caffe_maxpool, p.bufA, h->dt,
+                     p.img_pad, p.stem_out, s));
+    void *cur = p.bufA, *nxt = p.bufB;
+    int ch = p.Hs[0], cw = p.Ws[0];
+    for (int st = 0; st < 3; ++st)
+        for (auto &b : h->stages[st]) {
+            int ho, wo;
+            VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo));
+            std::swap(cur, nxt);
+            ch = ho;
+            cw = wo;
+        }
+    VK_REQUIRE(ch == p.Hf && cw == p.Wf, VK_EINVAL, "internal: res4 geometry mismatch (%dx%d vs %dx%d)", ch, cw, p.Hf, p.Wf);
+    const void *res4 = cur;
+    set_stage(h, "res4", res4, h->dt, {N, p.Hf, p.Wf, h->res4_c});
+    if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[1], s));
+
+    // ---- RPN head (RPNHead.forward frcnn.py:1561-1572) ----
+    const int ld_rpn = (5 * h->A + 7) / 8 * 8;
+    VK_TRY(run_conv(h, h->rpn_conv, res4, N, p.Hf, p.Wf, nullptr, p.rpn_hid, true, h->dt, 0, s));
+    VK_TRY(run_conv(h, h->rpn_heads, p.rpn_hid, N, p.Hf, p.Wf, nullptr, p.rpn_out, false, VK_F32, ld_rpn, s));
+    set_stage(h, "rpn_out", p.rpn_out, VK_F32, {N, p.Hf, p.Wf, ld_rpn});
+    if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[2], s));
+
+    // ---- proposals (RPN.inference frcnn.py:1615-1638) ----
+    VK_TRY(vk_rpn_proposals(p.rpn_out, ld_rpn, p.rpn_out + h->A, ld_rpn, N, p.Hf, p.Wf, h->A, h->cell_anchors, 16,
+                            c.anchor_offset, p.image_hw, c.rpn_bbox_weights, c.rpn_min_size, c.rpn_nms_thresh,
+                            c.pre_nms_topk, c.post_nms_topk, p.prop_boxes, p.prop_logits, p.prop_counts, p.nonfinite,
+                            p.rpn_ws, p.rpn_ws_bytes, s));
+    VK_TRY(launch_make_rois(p.prop_boxes, N, p.R, p.rois, s));
+    set_stage(h, "proposal_boxes", p.prop_boxes, VK_F32, {N, p.R, 4});
+    set_stage(h, "proposal_logits", p.prop_logits, VK_F32, {N, p.R});
+    set_stage(h, "proposal_counts", p.prop_counts, VK_I32, {N});
+    if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[3], s));
+
+    // ---- RoI heads (Res5ROIHeads.forward frcnn.py:1391-1403), chunked over RoIs ----
+    const int P = p.P, S = P * P;
+    for (int k0 = 0; k0 < p.K; k0 += p.chunk) {
+        const int kc = std::min(p.chunk, p.K - k0);
+        VK_TRY(vk_roi_pool(res4, N, p.Hf, p.Wf, h->res4_c, p.rois + 5 * (size_t)k0, kc, 1.0f / 16.0f, P, p.pooled, h->dt, s));
+        void *a = p.h_a, *b2 = p.h_b;
+        const void *x = p.pooled;
+        for (auto &blk : h->res5) {
+            int ho, wo;
+            VK_TRY(run_block(h, blk, x, kc, P, P, p.h_t1, p.h_t2, p.h_sc, a, s, &ho, &wo));
+            x = a;
+            std::swap(a, b2);
+        }
+        VK_TRY(vk_mean_pool(x, kc, S, h->res5_c, p.feat + (size_t)k0 * h->res5_c, h->dt, s));
+    }
+    if (p.chunk >= p.K) set_stage(h, "pooled", p.pooled, h->dt, {p.K, P, P, h->res4_c});
+    set_stage(h, "feature_pooled", p.feat, VK_F32, {p.K, h->res5_c});
+
+    // ---- box predictor (FastRCNNOutputLayers.forward frcnn.py:1726-1740) ----
+    const int C = c.num_classes, F = h->res5_c, E = h->emb_dim, AT = c.num_attrs;
+    const int ld_cls = (C + 1 + 7) / 8 * 8, ld_attr = (AT + 1 + 7) / 8 * 8;
+    VK_TRY(launch_concat_embed(p.feat, nullptr, nullptr, F, 0, p.K, p.featT, h->dt, s));
+    VK_TRY(run_conv(h, h->cls_score, p.featT, p.K, 1, 1, nullptr, p.cls_logits, false, VK_F32, ld_cls, s));
+    VK_TRY(launch_softmax_argmax(p.cls_logits, ld_cls, p.K, C + 1, C, p.obj_prob, p.obj_cls, p.max_class, s));
+    VK_TRY(launch_concat_embed(p.feat, h->emb, p.max_class, F, E, p.K, p.concat, h->dt, s));
+    VK_TRY(run_conv(h, h->fc_attr, p.concat, p.K, 1, 1, nullptr, p.attr_hid, true, h->dt, 0, s));
+    VK_TRY(run_conv(h, h->attr_score, p.attr_hid, p.K, 1, 1, nullptr, p.attr_logits, false, VK_F32, ld_attr, s));
+    VK_TRY(launch_softmax_argmax(p.attr_logits, ld_attr, p.K, AT, AT, p.attr_prob, p.attr_cls, nullptr, s));
+    VK_TRY(launch_chosen_deltas(p.featT, F, h->bbox_w, h->bbox_b, p.obj_cls, c.cls_agnostic_bbox_reg, F, p.K, p.chosen, h->dt, s));
+    set_stage(h, "obj_logits", p.cls_logits, VK_F32, {p.K, ld_cls});
+    set_stage(h, "attr_logits", p.attr_logits, VK_F32, {p.K, ld_attr});
+    set_stage(h, "chosen_deltas", p.chosen, VK_F32, {p.K, 4});
+    if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[4], s));
+
+    // ---- outputs (ROIOutputs.inference frcnn.py:1262-1294) ----
+    RoiFinalArgs a;
+    memset(&a, 0, sizeof(a));
+    a.obj_prob = p.obj_prob;
+    a.obj_cls = p.obj_cls;
+    a.attr_prob = p.attr_prob;
+    a.attr_cls = p.attr_cls;
+    a.box_deltas = p.chosen;
+    a.ld_box = 4;
+    a.delta_mode = 1;
+    a.proposals = p.prop_boxes;
+    a.counts = p.prop_counts;
+    a.features = p.feat;
+    a.F = F;
+    a.R = p.R;
+    a.D = D;
+    a.image_hw = p.image_hw;
+    a.scales_yx = scales_yx ? p.scales : nullptr;
+    a.wx = c.roi_bbox_weights[0];
+    a.wy = c.roi_bbox_weights[1];
+    a.ww = c.roi_bbox_weights[2];
+    a.wh = c.roi_bbox_weights[3];
+    a.clampv = (float)std::log(1000.0 / 16.0);
+    a.n_thresh = rp->num_nms_thresh;
+    for (int i = 0; i < rp->num_nms_thresh; ++i) a.thresh[i] = rp->nms_thresh[i];
+    a.mind = rp->min_detections;
+    a.maxd = rp->max_detections;
+    a.out = *out;
+    a.keep_ids = p.keep_ids;
+    a.nonfinite = p.nonfinite;
+    VK_TRY(launch_roi_final(a, N, s));
+    set_stage(h, "keep_ids", p.keep_ids, VK_I64, {N, D});
+    if (tm) {
+        VK_CHECK_HIP(hipEventRecord(h->ev[5], s));
+        h->ev_valid = true;
+    }
+
+    // the reference asserts finite boxes on the host (frcnn.py:148): one 4-byte read-back
+    int32_t flag = 0;
+    VK_CHECK_HIP(hipMemcpyAsync(&flag, p.nonfinite, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    VK_CHECK_HIP(hipStreamSynchronize(s));
+    VK_REQUIRE(flag == 0, VK_ENONFINITE, "Box tensor contains infinite or NaN!");
+    return VK_OK;
+}
+
+int vk_roi_outputs(const float *obj_logits, int ld_obj, const float *attr_logits, int ld_attr, const float *box_deltas,
+                   int ld_box, int chosen_only, const float *proposals, const int32_t *counts, const float *features, int F,
+                   int N, int R, int C, int A, const int32_t *image_hw, const float *scales_yx_dev,
+                   const float *weights4_host, const vk_roi_params *rp, const vk_outputs *out, int64_t *keep_ids_out,
+                   int32_t *nonfinite_flag, void *stream) {
+    VK_REQUIRE(obj_logits && box_deltas && proposals && counts && features && image_hw && rp && out && nonfinite_flag, VK_EINVAL,
+               "roi_outputs: null argument");
+    VK_REQUIRE(rp->num_nms_thresh >= 1 && rp->num_nms_thresh <= VK_MAX_NMS_THRESH, VK_EINVAL, "roi_outputs: 1..%d nms thresholds", VK_MAX_NMS_THRESH);
+    hipStream_t s = (hipStream_t)stream;
+    const int K = N * R;
+    // scratch for the per-RoI scores (freed after the stream drains; stage-level entry point only)
+    char *scratch = nullptr;
+    const size_t per = align_up((size_t)K * 4, 256);
+    VK_CHECK_HIP(hipMalloc((void **)&scratch, per * 4));
+    float *obj_prob = (float *)scratch, *attr_prob = (float *)(scratch + per);
+    int32_t *obj_cls = (int32_t *)(scratch + 2 * per), *attr_cls = (int32_t *)(scratch + 3 * per);
+    int st = launch_softmax_argmax(obj_logits, ld_obj, K, C + 1, C, obj_prob, obj_cls, nullptr, s);
+    if (st == VK_OK && attr_logits) st = launch_softmax_argmax(attr_logits, ld_attr, K, A, A, attr_prob, attr_cls, nullptr, s);
+    if (st == VK_OK) {
+        RoiFinalArgs a;
+        memset(&a, 0, sizeof(a));
+        a.obj_prob = obj_prob;
+        a.obj_cls = obj_cls;
+        a.attr_prob = attr_logits ? attr_prob : nullptr;
+        a.attr_cls = attr_logits ? attr_cls : nullptr;
+        a.box_deltas = box_deltas;
+        a.ld_box = ld_box;
+        a.delta_mode = chosen_only ? 1 : 0;
+        a.proposals = proposals;
+        a.counts = counts;
+        a.features = features;
+        a.F = F;
+        a.R = R;
+        a.D = rp->max_detections;
+        a.image_hw = image_hw;
+        a.scales_yx = scales_yx_dev;
+        a.wx = weights4_host[0];
+        a.wy = weights4_host[1];
+        a.ww = weights4_host[2];
+        a.wh = weights4_host[3];
+        a.clampv = (float)std::log(1000.0 / 16.0);
+        a.n_thresh = rp->num_nms_thresh;
+        for (int i = 0; i < rp->num_nms_thresh; ++i) a.thresh[i] = rp->nms_thresh[i];
+        a.mind = rp->min_detections;
+        a.maxd = rp->max_detections;
+        a.out = *out;
+        a.keep_ids = keep_ids_out;
+        a.nonfinite = nonfinite_flag;
+        st = launch_roi_final(a, N, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (st != VK_OK) return st;
+    VK_CHECK_HIP(e);
+    return VK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Internal helpers shared by the translation units of libvltk_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "vltk_hip.h"
+
+namespace vk {
+
+void set_error(const char *fmt, ...);
+
+#define VK_CHECK_HIP(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            vk::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return VK_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+#define VK_REQUIRE(cond, code, ...)       \
+    do {                                  \
+        if (!(cond)) {                    \
+            vk::set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define VK_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != VK_OK) return _s; \
+    } while (0)
+
+static inline size_t dtype_size(vk_dtype dt) {
+    switch (dt) {
+        case VK_F32: return 4;
+        case VK_F16: return 2;
+        case VK_I64: return 8;
+        case VK_I32: return 4;
+    }
+    return 0;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- convolution as implicit GEMM (conv_mfma.hip) --------------------------
+constexpr int CONV_BM = 128;        // output pixels per workgroup tile
+constexpr int CONV_KTILE_BYTES = 128;  // bytes of K per row per K-tile (64 f16 / 32 f32)
+constexpr int CONV_COUT_ALIGN = 128;   // packed weight rows are padded to this
+
+struct ConvArgs {
+    const void *x;       // NHWC input (or the padded NHWC4 image in stem mode)
+    const void *w;       // packed weights [cout_pad][ktiles * KTILE_BYTES]
+    const float *bias;   // [cout_pad]
+    const void *res;     // residual [M, ldy] or nullptr
+    void *y;             // output [M, ldy]
+    int N, H, W, Cin;    // input geometry (stem mode: padded Hp, Wp, 4)
+    int Ho, Wo, Cout, ldy;
+    int kh, kw, stride, pad, dil;
+    int relu;
+    int stem;            // 1: K-tiles are runs of consecutive input pixels (7x7 s2 stem)
+    vk_dtype dt, out_dt;
+};
+int launch_conv(const ConvArgs &a, hipStream_t stream);
+
+// ---- pool.hip ----
+int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s);
+int launch_maxpool(const void *x, void *y, int N, int H, int W, int C, int caffe, vk_dtype dt, hipStream_t s);
+
+// ---- roi_out.hip ----
+struct RoiFinalArgs {
+    const float *obj_prob;
+    const int32_t *obj_cls;
+    const float *attr_prob;
+    const int32_t *attr_cls;
+    const float *box_deltas;
+    int ld_box;
+    int delta_mode;   // 0: full [K,4C] (index cls*4), 1: already the chosen/agnostic 4 deltas
+    const float *proposals;
+    const int32_t *counts;
+    const float *features;
+    int F, R, D;
+    const int32_t *image_hw;
+    const float *scales_yx;
+    float wx, wy, ww, wh, clampv;
+    int n_thresh;
+    double thresh[VK_MAX_NMS_THRESH];
+    int mind, maxd;
+    vk_outputs out;
+    int64_t *keep_ids;
+    int32_t *nonfinite;
+};
+int launch_softmax_argmax(const float *logits, int ld, int K, int n_soft, int n_max, float *prob, int32_t *cls,
+                          int32_t *raw_argmax, hipStream_t s);
+int launch_concat_embed(const float *feat, const void *emb, const int32_t *cls, int F, int E, int K, void *out,
+                        vk_dtype dt, hipStream_t s);
+int launch_chosen_deltas(const void *x, int ldx, const void *w, const float *bias, const int32_t *cls, int agnostic, int F,
+                         int K, float *out, vk_dtype dt, hipStream_t s);
+int launch_roi_final(RoiFinalArgs &a, int N, hipStream_t s);
+int launch_make_rois(const float *boxes, int N, int R, float *rois, hipStream_t s);
+
+}  // namespace vk
