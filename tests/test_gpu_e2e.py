@@ -131,7 +131,12 @@ def test_e2e_fp16_fast_vs_emulating_oracle(setup, golden):
     m, out = run_gpu(cfg, sd, x, shapes, "fp16")
     oracle = FRCNNOracle(cfg, sd, emulate="fp16")
     res4 = nchw(m.get_stage("res4"))
-    assert G.rel_err(res4, oracle.backbone(x)) <= 1e-3
+    # free-running over 104 convolutions: summation-order differences flip single fp16 roundings
+    # (4.9e-4 each) which then propagate, so this one comparison is looser (5e-3); every stage is
+    # checked at 1e-3 below with the GPU's own upstream tensors as input.
+    e = G.rel_err(res4, oracle.backbone(x))
+    print(f"\n[fp16 vs fp16-emulating oracle, free-running backbone] res4 rel err {e:.3e}")
+    assert e <= 5e-3
     stage_chain_check(m, out, oracle, shapes, tol=1e-3)
     # reported: deviation of the fp16 pipeline from the fp32 reference
     dev = G.rel_err(res4, golden["res4"])

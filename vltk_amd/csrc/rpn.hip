@@ -313,8 +313,9 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const unsigned long long 
             for (int b = 0; b < 64; ++b) {
                 if (!((cur >> b) & 1ull)) {
                     kept |= 1ull << b;
-                    unsigned long long db = ((unsigned long long)__builtin_amdgcn_readlane(dhi, b) << 32) |
-                                            (unsigned long long)__builtin_amdgcn_readlane(dlo, b);
+                    // readlane returns a signed int: go through uint32_t or the low word sign-extends
+                    unsigned long long db = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
                     cur |= db;
                 }
             }
