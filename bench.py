@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of FRCNN feature extraction (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one vk_forward over one per-GPU batch of synthetic 800x1333 images already resident in HBM
+(ResNet-101-C4 fp16, R = 300 RPN proposals through the Res5 head, up to 100 detections per image),
+followed -- for N > 1 -- by the all-gather of the output blocks (RCCL).  Images shard across ranks
+(weak scaling: fixed per-GPU batch).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
+PEAK_F16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_gflop_per_image(R):
+    """SURVEY.md §8d algorithmic work (2*MAC) per 800x1333 image, R101-C4: backbone + RPN head + Res5 head."""
+    return 292.4 + 40.0 + 5.857 * R + 0.03554 * R
+
+
+def cpu_baseline(cfg, sd, R, det, seed):
+    """The oracle (CPU restatement of the reference path, torch CPU ops, all host cores) on ONE image."""
+    import torch
+    from oracle.frcnn_oracle import FRCNNOracle
+    from vltk_amd import synthetic_images
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)      # the 1-GPU box's CPU share (oversubscribing 256 visible cores is 10x slower)
+    torch.set_num_threads(cores)
+    o = FRCNNOracle(cfg, sd)
+    x = torch.from_numpy(synthetic_images(1, 800, 1333, seed=seed))
+    t0 = time.time()
+    out = o.forward(x, [[800, 1333]])
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image 800x1333, R={R}, D={det}, fp32, oracle/frcnn_oracle.py, {dt:.1f} s, "
+                      f"{int(out['preds_per_image'][0])} detections"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--proposals", type=int, default=300, help="RPN.POST_NMS_TOPK_TEST (RoIs through the Res5 head)")
+    ap.add_argument("--detections", type=int, default=100)
+    ap.add_argument("--head-chunk", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
+    from vltk_amd.parallel import gather_outputs
+    cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}")
+    sd = make_state_dict(cfg, seed=1234)
+    model = FRCNN(cfg, precision="fp16", device=f"cuda:{local_rank}").load_state_dict(sd).eval()
+    if a.head_chunk >= 0:
+        model.set_option("head_chunk", a.head_chunk)
+    B = a.batch
+    images = torch.from_numpy(synthetic_images(B, 800, 1333, seed=0xF2C, rank=rank)).cuda(local_rank)
+    shapes = torch.tensor([[800, 1333]] * B)
+
+    def step():
+        model(images, shapes, padding="max_detections", return_tensors="pt", location="cuda")
+        return gather_outputs(model.forward_padded())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    model.enable_kernel_timing(True)
+    model.kernel_timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kt = model.kernel_timing()
+    assert out["roi_features"].shape[0] == world * B
+
+    if rank == 0:
+        dom = kt["conv_f16_bn128"]
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        all_ms = sum(v["ms"] for v in kt.values())
+        all_fl = sum(v["flops"] for v in kt.values())
+        line = {
+            "metric": "images/sec FRCNN feature extraction, 800x1333 batch",
+            "value": round(world * B * a.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: ResNet-101-C4 fp16 (the reference has no FPN: SURVEY.md D1), "
+                                   f"{B} synthetic 800x1333 images per GPU per step, R={a.proposals} RPN proposals "
+                                   f"through the Res5 head, max {a.detections} detections/img, seeded synthetic weights",
+                       "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_mfma_kernel<f16,f16,BN=128> (implicit-GEMM conv, all launches of the timed region)",
+                         "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
+                         "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals), 1),
+                         "all_conv_kernels": {"ms_per_step": round(all_ms / a.steps, 3),
+                                              "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
+                                              "share_of_step": round(all_ms / (dt * 1e3), 4)}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, a.proposals, a.detections, seed=0xF2C)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,7 @@ struct ConvK {
     int wrow_bytes;      // ktiles * 128
     int relu;
     int m_tiles, n_tiles;
+    double alg_flops;    // 2 * M * Cout * (kh*kw*Cin): host-side bookkeeping only
 };
 
 template <typename T>
@@ -305,8 +306,21 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(k.m_tiles * k.n_tiles), block(256);
+    KernelTimer *tm = g_timer;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (tm) {
+        e0 = tm->get();
+        e1 = tm->get();
+        VK_CHECK_HIP(hipEventRecord(e0, stream));
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<T, OutT, BN, STEM>), grid, block, smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
+    if (tm) {
+        VK_CHECK_HIP(hipEventRecord(e1, stream));
+        int bucket = 3;
+        if (sizeof(T) == 2 && !STEM) bucket = sizeof(OutT) == 4 ? 2 : (BN == 128 ? 0 : 1);
+        tm->recs.push_back({bucket, k.alg_flops, e0, e1});
+    }
     return VK_OK;
 }
 
@@ -349,6 +363,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         k.ktiles = a.kh * a.kw * k.kt_per_tap;
     }
     k.wrow_bytes = k.ktiles * CONV_KTILE_BYTES;
+    k.alg_flops = 2.0 * (double)k.M * a.Cout * (a.stem ? 147.0 : (double)a.kh * a.kw * a.Cin);
     k.m_tiles = ceil_div(k.M, CONV_BM);
     const bool narrow = a.Cout <= 64 || a.stem;
     k.n_tiles = ceil_div(a.Cout, narrow ? 64 : 128);

@@ -21,6 +21,32 @@
 
 namespace vk {
 
+thread_local KernelTimer *g_timer = nullptr;
+
+hipEvent_t KernelTimer::get() {
+    if (used == pool.size()) {
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        pool.push_back(e);
+    }
+    return pool[used++];
+}
+void KernelTimer::collect() {
+    for (auto &r : recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            launches[r.bucket] += 1;
+            ms[r.bucket] += t;
+            flops[r.bucket] += r.flops;
+        }
+    }
+    recs.clear();
+    used = 0;
+}
+KernelTimer::~KernelTimer() {
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+
 static thread_local char g_err[1024] = "";
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -87,6 +113,7 @@ struct vk_handle {
         int ndim;
     };
     std::map<std::string, Stage> stages_out;
+    KernelTimer *ktimer = nullptr;
     bool timing = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -731,6 +758,7 @@ int vk_destroy(vk_handle *h) {
     if (h->arena) (void)hipFree(h->arena);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    delete h->ktimer;
     delete h;
     return VK_OK;
 }
@@ -798,6 +826,10 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
     }
     Plan p = make_plan(h, h->arena, N, H, W, D);
     h->stages_out.clear();
+    struct TimerScope {   // per-launch events only inside this forward
+        explicit TimerScope(KernelTimer *t) { g_timer = t; }
+        ~TimerScope() { g_timer = nullptr; }
+    } timer_scope(h->ktimer);
     const bool tm = h->timing;
     if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[0], s));
 
@@ -916,7 +948,34 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
     int32_t flag = 0;
     VK_CHECK_HIP(hipMemcpyAsync(&flag, p.nonfinite, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     VK_CHECK_HIP(hipStreamSynchronize(s));
+    if (h->ktimer) h->ktimer->collect();
     VK_REQUIRE(flag == 0, VK_ENONFINITE, "Box tensor contains infinite or NaN!");
+    return VK_OK;
+}
+
+int vk_enable_kernel_timing(vk_handle *h, int enable) {
+    VK_REQUIRE(h, VK_EINVAL, "null handle");
+    if (enable && !h->ktimer) h->ktimer = new KernelTimer();
+    if (!enable && h->ktimer) {
+        delete h->ktimer;
+        h->ktimer = nullptr;
+    }
+    return VK_OK;
+}
+
+int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, int reset) {
+    VK_REQUIRE(h && launches && ms && flops, VK_EINVAL, "null argument");
+    VK_REQUIRE(h->ktimer, VK_EINVAL, "kernel timing is not enabled");
+    for (int i = 0; i < VK_NUM_KERNEL_BUCKETS; ++i) {
+        launches[i] = h->ktimer->launches[i];
+        ms[i] = h->ktimer->ms[i];
+        flops[i] = h->ktimer->flops[i];
+        if (reset) {
+            h->ktimer->launches[i] = 0;
+            h->ktimer->ms[i] = 0;
+            h->ktimer->flops[i] = 0;
+        }
+    }
     return VK_OK;
 }
 

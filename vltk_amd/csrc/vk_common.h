@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "vltk_hip.h"
 
@@ -68,6 +69,25 @@ struct ConvArgs {
     vk_dtype dt, out_dt;
 };
 int launch_conv(const ConvArgs &a, hipStream_t stream);
+
+// optional per-launch event timing (set by vk_forward when enabled; thread-local)
+struct KernelTimer {
+    struct Rec {
+        int bucket;
+        double flops;
+        hipEvent_t e0, e1;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    int64_t launches[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
+    double ms[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
+    double flops[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
+    hipEvent_t get();
+    void collect();   // after the stream has been synchronised
+    ~KernelTimer();
+};
+extern thread_local KernelTimer *g_timer;
 
 // ---- pool.hip ----
 int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s);

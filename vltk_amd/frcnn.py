@@ -175,6 +175,18 @@ class FRCNN:
         L.call("vk_get_stage_timing", self._h, ms)
         return dict(zip(("backbone", "rpn_head", "proposals", "roi_heads", "predictor_outputs", "total"), list(ms)))
 
+    def enable_kernel_timing(self, on=True):
+        L.call("vk_enable_kernel_timing", self._h, int(on))
+
+    def kernel_timing(self, reset=False):
+        """Per-bucket (launches, ms, algorithmic flops) of the conv launches since the last reset."""
+        n = (C.c_int64 * 4)()
+        ms = (C.c_double * 4)()
+        fl = (C.c_double * 4)()
+        L.call("vk_get_kernel_timing", self._h, n, ms, fl, int(reset))
+        names = ("conv_f16_bn128", "conv_f16_bn64", "conv_f16_f32out", "other")
+        return {k: {"launches": int(n[i]), "ms": float(ms[i]), "flops": float(fl[i])} for i, k in enumerate(names)}
+
     def get_stage(self, name):
         """Intermediate tensor of the last forward as a torch tensor (a copy)."""
         ptr, dt, nd = C.c_void_p(), C.c_int(), C.c_int()
