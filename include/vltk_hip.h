@@ -114,7 +114,7 @@ int vk_load_weights(vk_handle *h, const char *name, const void *host_ptr,
 int vk_finalize(vk_handle *h);
 int vk_destroy(vk_handle *h);
 
-/* Tunables.  "head_chunk": RoIs per Res5-head chunk (0 = all RoIs in one pass; default 64 or
+/* Tunables.  "head_chunk": RoIs per Res5-head chunk (0 = all RoIs in one pass; default 1024 or
  * the VK_HEAD_CHUNK environment variable).  Results do not depend on it. */
 int vk_set_option(vk_handle *h, const char *key, int value);
 

@@ -1,0 +1,138 @@
+"""CPU (-m "not gpu"): host logic -- config semantics, weight layout, adapter plumbing, sharding
+and the world_size-2 gloo all-gather of the output blocks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from vltk_amd import adapters
+from vltk_amd.config import Config, vg_c4_config, vg_c4_config_dict
+from vltk_amd.parallel import OUTPUT_KEYS, shard_indices
+from vltk_amd.weights import layer_spec, make_state_dict, synthetic_images
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_dual_case_and_none(tmp_path):
+    cfg = vg_c4_config()
+    assert cfg.MODEL.DEVICE == cfg.model.device == "cpu"          # compat.py:133-135
+    assert cfg.min_detections == cfg.MIN_DETECTIONS == 36
+    assert cfg.RESNETS.DEPTH == 101 and cfg.ROI_BOX_HEAD.POOLER_RESOLUTION == 14
+    with pytest.raises(ValueError):
+        Config({"a": None})                                        # compat.py:119-120
+    cfg.dump_yaml(str(tmp_path / "config.yaml"))
+    again = Config.from_pretrained(str(tmp_path))                  # directory holding config.yaml
+    assert again.to_dict() == cfg.to_dict()
+    with pytest.raises(EnvironmentError):
+        Config.from_pretrained("unc-nlp/frcnn-vg-finetuned")       # fetch-by-name is not available
+
+
+def test_state_dict_layout_matches_reference_probe():
+    """640 tensors, 65.55 M elements, reference key names."""
+    cfg = vg_c4_config()
+    sd = make_state_dict(cfg, seed=1)
+    assert len(sd) == 640
+    assert abs(sum(v.size for v in sd.values()) / 1e6 - 65.55) < 0.01
+    assert sd["backbone.stem.conv1.weight"].shape == (64, 3, 7, 7)
+    assert sd["backbone.res4.22.conv3.norm.running_var"].shape == (1024,)
+    assert sd["proposal_generator.anchor_generator.cell_anchors.0"].shape == (15, 4)
+    assert sd["proposal_generator.rpn_head.conv.weight"].shape == (512, 1024, 3, 3)
+    assert sd["roi_heads.res5.0.shortcut.weight"].shape == (2048, 1024, 1, 1)
+    assert sd["roi_heads.box_predictor.cls_score.weight"].shape == (1601, 2048)
+    assert sd["roi_heads.box_predictor.bbox_pred.weight"].shape == (6400, 2048)
+    assert sd["roi_heads.box_predictor.cls_embedding.weight"].shape == (1601, 256)
+    assert sd["roi_heads.box_predictor.fc_attr.weight"].shape == (512, 2304)
+    assert sd["roi_heads.box_predictor.attr_score.weight"].shape == (401, 512)
+    # deterministic from the seed alone, independent of generation order
+    sd2 = make_state_dict(cfg, seed=1)
+    assert all(np.array_equal(sd[k], sd2[k]) for k in sd)
+    assert not np.array_equal(make_state_dict(cfg, seed=2)["backbone.stem.conv1.weight"], sd["backbone.stem.conv1.weight"])
+    assert len(layer_spec(vg_c4_config(depth=50))) < len(layer_spec(cfg))
+
+
+def test_synthetic_images_are_rank_distinct_and_bounded():
+    a, b = synthetic_images(1, 32, 48, rank=0), synthetic_images(1, 32, 48, rank=1)
+    assert a.shape == (1, 3, 32, 48) and a.dtype == np.float32
+    assert a.min() >= -123 and a.max() <= 152 and not np.array_equal(a, b)
+    assert np.array_equal(a, synthetic_images(1, 32, 48, rank=0))
+
+
+def test_adapter_surface():
+    A = adapters.Adapters()
+    assert "frcnn" in A.avail() and A.get("FRCNN") is adapters.FRCNN and A.is_extraction("frcnn")
+    sch = adapters.FRCNN.schema(max_detections=36, visual_dim=2048)
+    assert set(sch) == {"attr_ids", "object_ids", "features", "box"}        # adapters/frcnn.py:36-41
+    import inspect
+    assert list(inspect.signature(adapters.FRCNN.forward).parameters) == ["model", "entry"]   # extraction.py:60-68
+    with pytest.raises(EnvironmentError):
+        adapters.FRCNN.setup()          # no local checkpoint configured and not synthetic
+
+    class FakeModel:                    # the adapter only needs the model's call contract
+        def __call__(self, images, image_shapes, **kw):
+            assert images.shape == (1, 3, 20, 30) and image_shapes.tolist() == [[30, 20]]
+            assert kw["padding"] == "max_detections" and kw["location"] == "cpu"
+            return {"boxes": [torch.tensor([[10.0, 20.0, 30.0, 40.0]])], "obj_ids": [torch.tensor([7])],
+                    "attr_ids": [torch.tensor([3])], "roi_features": [torch.ones(1, 2048)]}
+    entry = {"image": torch.zeros(3, 20, 30), "size": torch.tensor([30, 20]), "wh_scale": torch.tensor([0.5, 0.25])}
+    out = adapters.FRCNN.forward(FakeModel(), entry)
+    assert out["object_ids"] == [[7]] and out["attr_ids"] == [[3]]
+    assert out["box"] == [[[20.0, 80.0, 60.0, 160.0]]]                     # rescale_box(boxes, 1/wh_scale), rounded
+    assert out["features"][0].shape == (1, 2048)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import vltk_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vltk_amd.FRCNN(vg_c4_config())
+    # and nothing under vltk_amd/ imports the oracle
+    for fn in os.listdir(os.path.join(ROOT, "vltk_amd")):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(ROOT, "vltk_amd", fn)).read().replace("oracle/", ""), fn
+
+
+def test_shard_indices_cover_everything():
+    for n, w in ((50000, 8), (7, 3), (3, 8), (32, 1)):
+        spans = [shard_indices(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from vltk_amd.parallel import gather_outputs, shard_indices, OUTPUT_KEYS
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+r = dist.get_rank()
+lo, hi = shard_indices(8, r, 2)
+B, D, F = hi - lo, 3, 16
+ids = torch.arange(lo, hi)
+pad = dict(obj_ids=(ids.view(B, 1) * 10 + torch.arange(D)).long(), obj_probs=torch.full((B, D), float(r)),
+           attr_ids=torch.zeros((B, D), dtype=torch.long), attr_probs=torch.zeros((B, D)),
+           boxes=ids.view(B, 1, 1).float().expand(B, D, 4).contiguous(), preds_per_image=ids.clone(),
+           roi_features=ids.view(B, 1, 1).float().expand(B, D, F).contiguous())
+out = gather_outputs(pad)
+assert list(out) == list(OUTPUT_KEYS)
+assert out["roi_features"].shape == (8, D, F)
+assert out["preds_per_image"].tolist() == list(range(8))          # image order == rank order of contiguous shards
+assert out["roi_features"][:, 0, 0].tolist() == [float(i) for i in range(8)]
+assert out["obj_probs"][:, 0].tolist() == [0.0] * 4 + [1.0] * 4
+dist.destroy_process_group()
+print("ok", r)
+"""
+
+
+def test_all_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

@@ -76,6 +76,7 @@ struct KernelTimer {
         int bucket;
         double flops;
         hipEvent_t e0, e1;
+        int M, cout, cin, k, stride;
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
