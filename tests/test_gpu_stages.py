@@ -41,6 +41,14 @@ CONV_CASES = [
     ("1x1_res", 2, 10, 13, 128, 512, 1, 1, 0, 1, True, True),
     ("3x3_s2", 1, 15, 16, 64, 128, 3, 2, 1, 1, False, True),
     ("1x1_big", 1, 40, 50, 512, 256, 1, 1, 0, 1, False, True),   # 2000 rows: several pixel tiles + an edge tile
+    # 256x256 LDS-ring kernel (Cout % 256 == 0, M >= 1024): K-stage ring lengths 2, 4, 6, 16, 18, 36 (fp16 packing makes the stage count even)
+    ("ring_s2", 2, 24, 24, 64, 256, 1, 1, 0, 1, False, False),
+    ("ring_s4", 2, 24, 24, 128, 512, 1, 1, 0, 1, True, True),
+    ("ring_s6", 1, 33, 37, 192, 256, 1, 1, 0, 1, True, True),
+    ("ring_1x1_k512", 2, 30, 50, 512, 1024, 1, 1, 0, 1, True, True),
+    ("ring_3x3", 2, 25, 31, 64, 256, 3, 1, 1, 1, False, True),
+    ("ring_3x3_dil2", 7, 14, 14, 128, 256, 3, 1, 2, 2, False, True),
+    ("ring_1x1_s2", 2, 47, 51, 256, 512, 1, 2, 0, 1, False, False),
 ]
 
 

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of vk_conv2d on the FRCNN layer shapes (GPU box).  Random data (never zeros:
+zero operands clock higher, cdna guide rule 25).  Usage: python tools/conv_bench.py [shape-name ...]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from vltk_amd import _lib as L   # noqa: E402
+import gpu_util as G             # noqa: E402
+
+# name: (N, H, W, cin, cout, k, stride, pad, dil, residual)
+SHAPES = {
+    "head_conv2": (1024, 14, 14, 512, 512, 3, 1, 2, 2, False),
+    "head_conv3": (1024, 14, 14, 512, 2048, 1, 1, 0, 1, True),
+    "head_conv1": (1024, 14, 14, 2048, 512, 1, 1, 0, 1, False),
+    "head_short": (1024, 14, 14, 1024, 2048, 1, 1, 0, 1, False),
+    "res4_conv3": (32, 50, 84, 256, 1024, 1, 1, 0, 1, True),
+    "res4_conv2": (32, 50, 84, 256, 256, 3, 1, 1, 1, False),
+    "res4_conv1": (32, 50, 84, 1024, 256, 1, 1, 0, 1, False),
+    "res2_conv3": (32, 200, 333, 64, 256, 1, 1, 0, 1, True),
+    "res3_conv3": (32, 100, 167, 128, 512, 1, 1, 0, 1, True),
+    "rpn_conv": (32, 50, 84, 1024, 512, 3, 1, 1, 1, False),
+}
+
+
+def main():
+    names = sys.argv[1:] or list(SHAPES)
+    iters = int(os.environ.get("ITERS", "10"))
+    g = np.random.Generator(np.random.PCG64(0))
+    for name in names:
+        N, H, W, cin, cout, k, stride, pad, dil, use_res = SHAPES[name]
+        w = (g.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+        wd, bd = G.pack_conv(w, None, np.zeros(cout, np.float32), L.VK_F16)
+        x = (torch.randn((N, H, W, cin), device=G.DEV) * 1.0).half()
+        Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.float16, device=G.DEV)
+        res = torch.randn((N, Ho, Wo, cout), device=G.DEV).half() if use_res else None
+
+        def run():
+            L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad,
+                   dil, 1, L.VK_F16, L.VK_F16, G.stream())
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        M = N * Ho * Wo
+        fl = 2.0 * M * cout * cin * k * k
+        by = 2.0 * (M * cin + M * cout * (2 if use_res else 1) + cout * cin * k * k)
+        print(f"{name:12s} M={M:8d} cout={cout:5d} K={cin * k * k:5d} {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TFLOP/s "
+              f"{by / ms / 1e6:8.1f} GB/s(alg)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -264,34 +264,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     }
 
     // ---- epilogue: + bias (+ residual) (ReLU) -> OutT, 8 consecutive channels per lane ----
+    // residual loads of a channel group are issued together (clamped row, predicated store)
 #pragma unroll
     for (int qn = 0; qn < NI / 2; ++qn) {
         const int co = n0 + wn * (BN / 2) + qn * 32 + g * 8;
         if (co >= p.cout8) continue;
         float b[8];
         load8<float>(reinterpret_cast<const char *>(p.bias + co), b);
+        float rr[4][8];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (p.res) {
+                const int m = min(m0 + wm * 64 + mi * 16 + j, p.M - 1);
+                load8<T>(p.res + ((long)m * p.ldy + co) * ES, rr[mi]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rr[mi][e] = 0.f;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + j;
-            if (m >= p.M) continue;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = acc[mi][2 * qn][e] + b[e];
-                v[4 + e] = acc[mi][2 * qn + 1][e] + b[4 + e];
-            }
-            const long idx = (long)m * p.ldy + co;
-            if (p.res) {
-                float rr[8];
-                load8<T>(p.res + idx * ES, rr);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                v[e] = acc[mi][2 * qn][e] + b[e] + rr[mi][e];
+                v[4 + e] = acc[mi][2 * qn + 1][e] + b[4 + e] + rr[mi][4 + e];
             }
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
-            store8<OutT>(p.y + idx * (long)sizeof(OutT), v);
+            if (m < p.M) store8<OutT>(p.y + ((long)m * p.ldy + co) * (long)sizeof(OutT), v);
         }
     }
 }
@@ -325,6 +329,7 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
+    if (conv256_eligible(a)) return launch_conv256(a, stream);
     const int es = (int)dtype_size(a.dt);
     VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32, VK_EINVAL, "conv: dtype must be f16 or f32");
     VK_REQUIRE(a.out_dt == a.dt || a.out_dt == VK_F32, VK_EINVAL, "conv: out dtype must equal dtype or be f32");

@@ -1,0 +1,400 @@
+// 256x256-tile implicit-GEMM convolution for the FLOP-heavy layers (Res5 head, res3/res4, RPN 3x3):
+// same contract as conv_mfma.hip (NHWC fp16 in, fp32 accumulate, + bias (+ residual)(+ ReLU),
+// fp16 out), built for one 512-thread workgroup (8 waves, 2 x 4) per CU.
+//
+// Structure (CDNA4-specific):
+//   * K advances in stages of 32 channels (64 B per row).  LDS is a RING of 4 stage slots
+//     (4 x (256 pixel rows + 256 channel rows) x 64 B = 128 KiB); stage s+4 is requested while
+//     stage s is finishing, so three stages of HBM/L2 latency are always in flight per CU.
+//   * global -> LDS goes through the LDS-DMA path (global_load_lds_dwordx4, 16 B per lane, no
+//     VGPR staging).  The LDS image must be lane-linear per wave-instruction, so the XOR swizzle
+//     that makes the ds_read_b128 fragment reads conflict-free (64-B rows: phys chunk =
+//     chunk ^ (-(row>>2) & 3)) is applied to each lane's SOURCE address.  im2col gather = the
+//     per-lane source address; out-of-image taps and rows beyond M read a zero page.
+//   * one raw s_barrier per stage (32 MFMAs per wave), placed three quarters through the stage:
+//     wait vmcnt(8) (stage s+1 landed; s+2, s+3 still in flight) -> lgkmcnt(0) -> barrier -> request
+//     stage s+4 into the slot of stage s (every wave has finished reading it) -> read the weight
+//     fragments of stage s+1.  Pixel-row fragments stream through a 4-deep register window, read
+//     two row-tiles ahead of the 4 MFMAs (v_mfma_f32_16x16x32_f16) that consume them, across the
+//     stage boundary, so LDS latency is always covered by MFMAs of the same wave.
+//   * per-wave output 128 x 64 (8 x 4 accumulator tiles, 128 accumulator registers); the weight
+//     fragment is the MFMA A operand so a lane owns 8 consecutive output channels = one 16-byte
+//     NHWC store, as in conv_mfma.hip.
+#include <type_traits>
+
+#include "vk_common.h"
+
+namespace vk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct Conv256K {
+    const char *x;
+    const char *w;
+    const float *bias;
+    const char *res;
+    char *y;
+    const char *zero;    // >= 16 B of zeros (source of padded taps / rows beyond M)
+    int H, W, Ho, Wo, HoWo, M;
+    int cin_bytes, ldy;
+    int kw, stride, pad, dil;
+    int stages, st_per_tap;   // K stages of 32 channels
+    int wrow_bytes;
+    int relu;
+    int m_tiles, n_tiles;
+};
+
+constexpr int R_BM = 256, R_BN = 256, R_ROWB = 64, R_NSLOT = 4;
+constexpr int R_XB = R_BM * R_ROWB;          // 16 KiB
+constexpr int R_SLOT = 2 * R_XB;             // 32 KiB
+constexpr int R_SMEM = R_NSLOT * R_SLOT;     // 128 KiB
+
+#define VK_GLDS16(gptr, lptr)                                                                          \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// DBG != 0 are timing-only diagnostic builds (wrong results): 1 = no LDS-DMA in the steady state,
+// 2 = no pixel-row fragment reads, 3 = both.  Selected with VK_CONV256_DBG; never used by the product path.
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int n_tile = t % p.n_tiles, m_tile = t / p.n_tiles;
+    const int m0 = m_tile * R_BM, n0 = n_tile * R_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, j = lane & 15;
+
+    // ---- LDS-DMA source state: this lane feeds rows (wave*2+i)*16 + (lane>>2), i = 0,1 ----
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);   // logical 16-B chunk whose bytes land at phys chunk lane&3
+    long a_off[2];
+    int bh[2], bw[2];
+    const char *wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + lrow;
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n_img = mm / p.HoWo;
+        const int rem = mm - n_img * p.HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+        a_off[i] = ((long)(n_img * p.H + h0) * p.W + w0) * p.cin_bytes + lchunk * 16;
+        bh[i] = ok ? h0 : -(1 << 28);
+        bw[i] = w0;
+        wsrc[i] = p.w + (long)(n0 + row) * p.wrow_bytes + lchunk * 16;
+    }
+    const int dma_x0 = (wave * 2) * 1024;               // byte offset of this wave's first X row block in a slot
+    const int dma_w0 = R_XB + (wave * 2) * 1024;
+
+    // An LDS-DMA instruction is slow to ISSUE (~60-180 cycles), so the 4 pieces of a stage are never
+    // issued back to back: each one follows a group of 4 MFMAs that keeps the matrix pipe busy meanwhile.
+    int khi = 0, kwi = 0, kc = 0;   // tap / channel-stage of the NEXT pixel-row request
+    const char *xsrc[2];
+    auto prep_x = [&]() {           // source addresses of the next stage's two pixel-row pieces
+        const int dh = khi * p.dil, dw = kwi * p.dil;
+        const long toff = ((long)dh * p.W + dw) * p.cin_bytes + kc * R_ROWB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = (unsigned)(bh[i] + dh) < (unsigned)p.H && (unsigned)(bw[i] + dw) < (unsigned)p.W;
+            xsrc[i] = ok ? p.x + a_off[i] + toff : p.zero;
+        }
+        // branch-free advance of (kernel row, kernel col, channel stage): keeps the K loop one basic block
+        kc += 1;
+        const int c1 = (kc == p.st_per_tap) ? 1 : 0;
+        kc *= (1 - c1);
+        kwi += c1;
+        const int c2 = (kwi == p.kw) ? 1 : 0;
+        kwi *= (1 - c2);
+        khi += c2;
+    };
+    auto req_x = [&](int stage, int i) {
+        if constexpr (DBG & 1) return;
+        VK_GLDS16(xsrc[i], smem + (stage & (R_NSLOT - 1)) * R_SLOT + dma_x0 + i * 1024);
+    };
+    auto req_w = [&](int stage, int i) {
+        if constexpr (DBG & 1) return;
+        VK_GLDS16(wsrc[i] + (long)stage * R_ROWB, smem + (stage & (R_NSLOT - 1)) * R_SLOT + dma_w0 + i * 1024);
+    };
+
+    // ---- fragment read addresses (bytes inside a slot) ----
+    const int sx = (-(j >> 2)) & 3;
+    const int x_addr = (wr * 128 + j) * R_ROWB + ((g ^ sx) << 4);                       // + mi*1024
+    int w_addr[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int wrow = wc * 64 + (j >> 2) * 8 + par * 4 + (j & 3);                    // + (ni>>1)*32 rows
+        w_addr[par] = R_XB + wrow * R_ROWB + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
+    }
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // Fragment registers: two weight sets (current / next stage) and a 4-deep rotating window of
+    // pixel-row fragments read two row-tiles ahead of the MFMAs that consume them.
+    //
+    // hipcc waits lgkmcnt(0) at every use of a compiler-issued ds_read while an LDS-DMA is in flight
+    // (verified in the ISA), which would expose the full LDS latency every row.  The fragment reads
+    // and their COUNTED waits are therefore issued by hand: LDS returns in order, so with reads issued
+    // as  w'0..w'3, x0, x1, [x2 | wait 2 | mma0], [x3 | wait 2 | mma1], ...  "all but the 2 newest"
+    // is exactly "row r and everything before it".  Each wait names its row register "+v" so the
+    // MFMAs that consume it cannot be scheduled above it.
+    half8 wa[4], wb[4], xw[4];
+    const int S = p.stages;
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned x_a = lds0 + x_addr, w_a0 = lds0 + w_addr[0], w_a1 = lds0 + w_addr[1];
+
+#define VK_DSR(dst, addr, OFF)                                                                \
+    do {                                                                                      \
+        if constexpr (DBG & 2)                                                                \
+            asm volatile("" : "+v"(dst) : "v"(addr));                                         \
+        else                                                                                  \
+            asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr));         \
+    } while (0)
+#define VK_WAIT2(reg) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(reg))
+#define VK_MMA_ROW(MI, XR, WF)                                                                       \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                                   \
+        __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0)
+#define VK_READ_W(WF, so)          \
+    VK_DSR(WF[0], w_a0 + so, 0);   \
+    VK_DSR(WF[1], w_a1 + so, 0);   \
+    VK_DSR(WF[2], w_a0 + so, 2048); \
+    VK_DSR(WF[3], w_a1 + so, 2048)
+
+    // stage s+1 landed <=> at most the pieces of stages s+2, s+3 (4 each) are still outstanding
+    // (the pixel pieces of stage s+4 are only issued after this wait)
+    auto wait_next = [&](int s) {
+        if (s + 3 < S)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s + 2 < S)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // FULL: steady state (stage s+4 exists): constant waits, no branches.  !FULL: the last stages.
+    auto stage_body = [&](auto full_c, int s, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const bool more = FULL || (s + 1 < S);
+        const unsigned so = (unsigned)(s & (R_NSLOT - 1)) * R_SLOT;           // this stage's slot
+        const unsigned sn = (unsigned)((s + 1) & (R_NSLOT - 1)) * R_SLOT;     // next stage's slot
+        const unsigned xs = x_a + so, xn = x_a + sn;
+        const bool rw = FULL || (s + 3 < S);      // weight pieces of stage s+3 ride on rows 0, 1
+        const bool rx = FULL || (s + 4 < S);      // pixel pieces of stage s+4 ride on rows 6, 7 (after the barrier)
+        // rows 0..5: read row r+2 of this stage, wait for row r, 4 MFMAs
+        VK_DSR(xw[2], xs, 2048); VK_WAIT2(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(0, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
+        if (rw) req_w(s + 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[3], xs, 3072); VK_WAIT2(xw[1]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(1, xw[1], wcur); __builtin_amdgcn_sched_barrier(0);
+        if (rw) req_w(s + 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[0], xs, 4096); VK_WAIT2(xw[2]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(2, xw[2], wcur); __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[1], xs, 5120); VK_WAIT2(xw[3]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(3, xw[3], wcur); __builtin_amdgcn_sched_barrier(0);
+        if (rx) prep_x();                        // address arithmetic for the rows-6/7 pieces, off the critical path
+        VK_DSR(xw[2], xs, 6144); VK_WAIT2(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(4, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[3], xs, 7168); VK_WAIT2(xw[1]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(5, xw[1], wcur); __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            // every read of stage s has been issued; once they are complete (lgkmcnt(0)) and every wave is
+            // here, slot (s+4)&3 == slot(s) is free, and every wave's DMA of stage s+1 has landed (vmcnt:
+            // all but the 8 pieces of stages s+2, s+3)
+            if constexpr (FULL)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                wait_next(s);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[2]), "+v"(xw[3])::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            VK_READ_W(wnext, sn);
+            VK_DSR(xw[0], xn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            VK_MMA_ROW(6, xw[2], wcur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rx) req_x(s + 4, 0);
+            VK_DSR(xw[1], xn, 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            VK_MMA_ROW(7, xw[3], wcur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rx) req_x(s + 4, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[2]), "+v"(xw[3]));
+            __builtin_amdgcn_sched_barrier(0);
+            VK_MMA_ROW(6, xw[2], wcur);
+            VK_MMA_ROW(7, xw[3], wcur);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+
+    // prologue: stages 0..2 completely, and the pixel rows of stage 3 (its weight rows ride on stage 0)
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st < S) {
+            prep_x();
+            req_x(st, 0);
+            req_x(st, 1);
+            issued += 2;
+            if (st < 3) {
+                req_w(st, 0);
+                req_w(st, 1);
+                issued += 2;
+            }
+        }
+    }
+    // stage 0 (the 4 oldest pieces) must have landed
+    if (issued == 14)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (issued == 12)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (issued == 8)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    VK_READ_W(wa, 0u);
+    VK_DSR(xw[0], x_a, 0);
+    VK_DSR(xw[1], x_a, 1024);
+    int s = 0;
+    for (; s + 5 < S; s += 2) {
+        stage_body(T_{}, s, wa, wb);
+        stage_body(T_{}, s + 1, wb, wa);
+    }
+    for (; s < S; s += 2) {
+        stage_body(F_{}, s, wa, wb);
+        if (s + 1 < S) stage_body(F_{}, s + 1, wb, wa);
+    }
+#undef VK_DSR
+#undef VK_WAIT2
+#undef VK_MMA_ROW
+#undef VK_READ_W
+
+    // ---- epilogue: + bias (+ residual) (ReLU) -> f16, 8 consecutive channels per lane ----
+    // The 8 residual loads of a channel group are issued together (addresses clamped to a valid row,
+    // only the store is predicated) so their HBM latency overlaps instead of serialising.
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const int co = n0 + wc * 64 + qn * 32 + g * 8;
+        const floatx4 b0 = reinterpret_cast<const floatx4 *>(p.bias + co)[0];
+        const floatx4 b1 = reinterpret_cast<const floatx4 *>(p.bias + co)[1];
+        half8 rr[8];
+        if (p.res) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = min(m0 + wr * 128 + mi * 16 + j, p.M - 1);
+                rr[mi] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + co) * 2);
+            }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) rr[mi] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wr * 128 + mi * 16 + j;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[mi][2 * qn][e] + b0[e] + (float)rr[mi][e];
+                v[4 + e] = acc[mi][2 * qn + 1][e] + b1[e] + (float)rr[mi][4 + e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + co) * 2) = o;
+        }
+    }
+}
+
+bool conv256_eligible(const ConvArgs &a) {
+    static const bool disabled = getenv("VK_DISABLE_CONV256") != nullptr;
+    if (disabled || a.stem) return false;
+    if (a.dt != VK_F16 || a.out_dt != VK_F16) return false;
+    if (a.Cout % R_BN != 0 || a.ldy != a.Cout) return false;
+    if (a.Cin % 32 != 0) return false;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    return M >= 4 * R_BM;
+}
+
+int launch_conv256(const ConvArgs &a, hipStream_t stream) {
+    static char *zero_page = nullptr;
+    if (!zero_page) {
+        VK_CHECK_HIP(hipMalloc((void **)&zero_page, 256));
+        VK_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        attr_set = true;
+    }
+    Conv256K k;
+    k.x = (const char *)a.x;
+    k.w = (const char *)a.w;
+    k.bias = a.bias;
+    k.res = (const char *)a.res;
+    k.y = (char *)a.y;
+    k.zero = zero_page;
+    k.H = a.H;
+    k.W = a.W;
+    k.Ho = a.Ho;
+    k.Wo = a.Wo;
+    k.HoWo = a.Ho * a.Wo;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    VK_REQUIRE(M > 0 && M < (1L << 31) - R_BM, VK_EINVAL, "conv256: M=%ld out of range", M);
+    k.M = (int)M;
+    k.cin_bytes = a.Cin * 2;
+    k.ldy = a.ldy;
+    k.kw = a.kw;
+    k.stride = a.stride;
+    k.pad = a.pad;
+    k.dil = a.dil;
+    k.st_per_tap = a.Cin / 32;
+    k.stages = a.kh * a.kw * k.st_per_tap;
+    k.wrow_bytes = a.kh * a.kw * a.Cin * 2;
+    k.relu = a.relu;
+    k.m_tiles = ceil_div(k.M, R_BM);
+    k.n_tiles = a.Cout / R_BN;
+    KernelTimer *tm = g_timer;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (tm) {
+        e0 = tm->get();
+        e1 = tm->get();
+        VK_CHECK_HIP(hipEventRecord(e0, stream));
+    }
+    static const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
+    const dim3 grid(k.m_tiles * k.n_tiles), block(512);
+    switch (dbg) {
+        case 1: hipLaunchKernelGGL(conv_mfma256_kernel<1>, grid, block, R_SMEM, stream, k); break;
+        case 2: hipLaunchKernelGGL(conv_mfma256_kernel<2>, grid, block, R_SMEM, stream, k); break;
+        case 3: hipLaunchKernelGGL(conv_mfma256_kernel<3>, grid, block, R_SMEM, stream, k); break;
+        default: hipLaunchKernelGGL(conv_mfma256_kernel<0>, grid, block, R_SMEM, stream, k);
+    }
+    VK_CHECK_HIP(hipGetLastError());
+    if (tm) {
+        VK_CHECK_HIP(hipEventRecord(e1, stream));
+        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride});
+    }
+    return VK_OK;
+}
+
+}  // namespace vk

@@ -69,6 +69,8 @@ struct ConvArgs {
     vk_dtype dt, out_dt;
 };
 int launch_conv(const ConvArgs &a, hipStream_t stream);
+bool conv256_eligible(const ConvArgs &a);                 // conv_mfma256.hip
+int launch_conv256(const ConvArgs &a, hipStream_t stream);
 
 // optional per-launch event timing (set by vk_forward when enabled; thread-local)
 struct KernelTimer {
