@@ -111,7 +111,7 @@ def main():
     assert out["roi_features"].shape[0] == world * B
 
     if rank == 0:
-        dom = kt["conv_f16_bn128"]
+        dom = kt["conv_mfma256"]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         all_ms = sum(v["ms"] for v in kt.values())
         all_fl = sum(v["flops"] for v in kt.values())
@@ -126,7 +126,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_mfma_kernel<f16,f16,BN=128> (implicit-GEMM conv, all launches of the timed region)",
+                         "kernel": "conv_mfma256_kernel (256x256 LDS-ring implicit-GEMM conv, f16 in / f32 acc; all launches of the timed region)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
                          "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals), 1),
                          "all_conv_kernels": {"ms_per_step": round(all_ms / a.steps, 3),

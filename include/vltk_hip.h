@@ -154,8 +154,8 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
 
 /* Per-kernel timing of the forward's convolution launches (HIP events on the launch stream around
  * every launch; read after the forward's own end-of-call synchronisation, accumulated until reset).
- * bucket 0: conv f16->f16, 128-channel tile (the dominant kernel)   1: conv f16->f16, 64-channel tile
- * bucket 2: conv f16->f32 out (RPN heads, predictor GEMMs)          3: f32 strict-mode convs / stem
+ * bucket 0: conv_mfma256_kernel (256x256 LDS-ring tile; the dominant kernel)   1: conv_mfma_kernel f16->f16 (128x{64,128} tile)
+ * bucket 2: conv_mfma_kernel f16->f32 out (RPN heads, predictor GEMMs)          3: f32 strict-mode convs / stem
  * launches[4], ms[4], flops[4] (algorithmic 2*M*Cout*K of the launches, doubles). */
 #define VK_NUM_KERNEL_BUCKETS 4
 int vk_enable_kernel_timing(vk_handle *h, int enable);

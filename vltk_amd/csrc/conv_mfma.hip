@@ -322,7 +322,7 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         int bucket = 3;
-        if (sizeof(T) == 2 && !STEM) bucket = sizeof(OutT) == 4 ? 2 : (BN == 128 ? 0 : 1);
+        if (sizeof(T) == 2 && !STEM) bucket = sizeof(OutT) == 4 ? 2 : 1;
         tm->recs.push_back({bucket, k.alg_flops, e0, e1, k.M, k.cout8, k.cin_bytes / (int)sizeof(T), k.ktiles / k.kt_per_tap, k.stride});
     }
     return VK_OK;

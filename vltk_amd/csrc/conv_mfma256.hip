@@ -60,6 +60,9 @@ template <int DBG>
 __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // XCD-aware (bijective) workgroup -> tile map (see conv_mfma.hip).  A persistent-workgroup variant
+    // (tile loop inside the kernel) was tried and rejected: the loop-carried state pushed the kernel over
+    // the 256-VGPR budget (79 spilled registers, 8-25 % slower on every shape).
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -143,12 +146,12 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     // Fragment registers: two weight sets (current / next stage) and a 4-deep rotating window of
-    // pixel-row fragments read two row-tiles ahead of the MFMAs that consume them.
+    // pixel-row fragments read three row-tiles ahead of the MFMAs that consume them.
     //
     // hipcc waits lgkmcnt(0) at every use of a compiler-issued ds_read while an LDS-DMA is in flight
     // (verified in the ISA), which would expose the full LDS latency every row.  The fragment reads
     // and their COUNTED waits are therefore issued by hand: LDS returns in order, so with reads issued
-    // as  w'0..w'3, x0, x1, [x2 | wait 2 | mma0], [x3 | wait 2 | mma1], ...  "all but the 2 newest"
+    // as  w'0..w'3, x0, x1, x2, [x3 | wait 3 | mma0], [x4 | wait 3 | mma1], ...  "all but the 3 newest"
     // is exactly "row r and everything before it".  Each wait names its row register "+v" so the
     // MFMAs that consume it cannot be scheduled above it.
     half8 wa[4], wb[4], xw[4];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         else                                                                                  \
             asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr));         \
     } while (0)
-#define VK_WAIT2(reg) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(reg))
+#define VK_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
 #define VK_MMA_ROW(MI, XR, WF)                                                                       \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                                   \
         __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0)
@@ -191,19 +194,20 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         const unsigned sn = (unsigned)((s + 1) & (R_NSLOT - 1)) * R_SLOT;     // next stage's slot
         const unsigned xs = x_a + so, xn = x_a + sn;
         const bool rw = FULL || (s + 3 < S);      // weight pieces of stage s+3 ride on rows 0, 1
-        const bool rx = FULL || (s + 4 < S);      // pixel pieces of stage s+4 ride on rows 6, 7 (after the barrier)
-        // rows 0..5: read row r+2 of this stage, wait for row r, 4 MFMAs
-        VK_DSR(xw[2], xs, 2048); VK_WAIT2(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(0, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
+        const bool rx = FULL || (s + 4 < S);      // pixel pieces of stage s+4 ride on rows 5, 6 (after the barrier)
+        // rows 0..4: read row r+3 of this stage, wait for row r (all but the 3 newest reads), 4 MFMAs.
+        // The DMA pieces ride behind MFMA groups: weights of stage s+3 on rows 0-1, pixels of stage s+4
+        // on rows 5-6 (after the barrier that frees their slot).
+        VK_DSR(xw[3], xs, 3072); VK_WAIT3(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(0, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
         if (rw) req_w(s + 3, 0);
         __builtin_amdgcn_sched_barrier(0);
-        VK_DSR(xw[3], xs, 3072); VK_WAIT2(xw[1]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(1, xw[1], wcur); __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[0], xs, 4096); VK_WAIT3(xw[1]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(1, xw[1], wcur); __builtin_amdgcn_sched_barrier(0);
         if (rw) req_w(s + 3, 1);
         __builtin_amdgcn_sched_barrier(0);
-        VK_DSR(xw[0], xs, 4096); VK_WAIT2(xw[2]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(2, xw[2], wcur); __builtin_amdgcn_sched_barrier(0);
-        VK_DSR(xw[1], xs, 5120); VK_WAIT2(xw[3]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(3, xw[3], wcur); __builtin_amdgcn_sched_barrier(0);
-        if (rx) prep_x();                        // address arithmetic for the rows-6/7 pieces, off the critical path
-        VK_DSR(xw[2], xs, 6144); VK_WAIT2(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(4, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
-        VK_DSR(xw[3], xs, 7168); VK_WAIT2(xw[1]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(5, xw[1], wcur); __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[1], xs, 5120); VK_WAIT3(xw[2]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(2, xw[2], wcur); __builtin_amdgcn_sched_barrier(0);
+        if (rx) prep_x();                        // address arithmetic for the rows-5/6 pieces, off the critical path
+        VK_DSR(xw[2], xs, 6144); VK_WAIT3(xw[3]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(3, xw[3], wcur); __builtin_amdgcn_sched_barrier(0);
+        VK_DSR(xw[3], xs, 7168); VK_WAIT3(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(4, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
         if (more) {
             // every read of stage s has been issued; once they are complete (lgkmcnt(0)) and every wave is
             // here, slot (s+4)&3 == slot(s) is free, and every wave's DMA of stage s+1 has landed (vmcnt:
@@ -212,23 +216,27 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else
                 wait_next(s);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[2]), "+v"(xw[3])::"memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
             __builtin_amdgcn_sched_barrier(0);
             VK_READ_W(wnext, sn);
             VK_DSR(xw[0], xn, 0);
             __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(6, xw[2], wcur);
+            VK_MMA_ROW(5, xw[1], wcur);
             __builtin_amdgcn_sched_barrier(0);
             if (rx) req_x(s + 4, 0);
             VK_DSR(xw[1], xn, 1024);
             __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(7, xw[3], wcur);
+            VK_MMA_ROW(6, xw[2], wcur);
             __builtin_amdgcn_sched_barrier(0);
             if (rx) req_x(s + 4, 1);
+            VK_DSR(xw[2], xn, 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            VK_MMA_ROW(7, xw[3], wcur);
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[2]), "+v"(xw[3]));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
             __builtin_amdgcn_sched_barrier(0);
+            VK_MMA_ROW(5, xw[1], wcur);
             VK_MMA_ROW(6, xw[2], wcur);
             VK_MMA_ROW(7, xw[3], wcur);
         }
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     VK_READ_W(wa, 0u);
     VK_DSR(xw[0], x_a, 0);
     VK_DSR(xw[1], x_a, 1024);
+    VK_DSR(xw[2], x_a, 2048);
     int s = 0;
     for (; s + 5 < S; s += 2) {
         stage_body(T_{}, s, wa, wb);
@@ -275,47 +284,66 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         if (s + 1 < S) stage_body(F_{}, s + 1, wb, wa);
     }
 #undef VK_DSR
-#undef VK_WAIT2
+#undef VK_WAIT3
 #undef VK_MMA_ROW
 #undef VK_READ_W
 
-    // ---- epilogue: + bias (+ residual) (ReLU) -> f16, 8 consecutive channels per lane ----
-    // The 8 residual loads of a channel group are issued together (addresses clamped to a valid row,
-    // only the store is predicated) so their HBM latency overlaps instead of serialising.
+    // ---- epilogue: + bias (+ residual) (ReLU) -> f16, through LDS so that HBM sees whole lines ----
+    // In the accumulator layout a wave-instruction touches 16 rows x 64 B (half cache lines), and the
+    // per-CU memory pipeline (not HBM) bounds the epilogue of the small-K layers.  The ring is dead now,
+    // so the f32 tile goes through LDS in two 128-row halves ([128][256] f32 = 128 KiB, 16-B chunks
+    // XOR-swizzled by row) and is read back row-contiguous: every residual load and every store of a
+    // wave covers 2 rows x 512 B = 8 whole 128-B lines.
+    asm volatile("s_barrier" ::: "memory");          // every wave has finished reading its fragments
+    floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn) {
-        const int co = n0 + wc * 64 + qn * 32 + g * 8;
-        const floatx4 b0 = reinterpret_cast<const floatx4 *>(p.bias + co)[0];
-        const floatx4 b1 = reinterpret_cast<const floatx4 *>(p.bias + co)[1];
-        half8 rr[8];
-        if (p.res) {
+    for (int h = 0; h < 2; ++h) {
+        if (wr == h) {
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = min(m0 + wr * 128 + mi * 16 + j, p.M - 1);
-                rr[mi] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + co) * 2);
+            for (int qn = 0; qn < 2; ++qn) {
+                const int col = wc * 64 + qn * 32 + g * 8;              // tile-local channel of this lane's 8 values
+                const floatx4 b0 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[0];
+                const floatx4 b1 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[1];
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int row = mi * 16 + j;
+                    const int c16 = col >> 2;
+                    stg[row * 64 + (c16 ^ (row & 7))] = acc[mi][2 * qn] + b0;
+                    stg[row * 64 + ((c16 + 1) ^ (row & 7))] = acc[mi][2 * qn + 1] + b1;
+                }
             }
-        } else {
+        }
+        __syncthreads();
+        half8 rr[8];
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) rr[mi] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
+            const int m = min(m0 + h * 128 + row, p.M - 1);
+            if (p.res)
+                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
+            else
+                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + wr * 128 + mi * 16 + j;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[mi][2 * qn][e] + b0[e] + (float)rr[mi][e];
-                v[4 + e] = acc[mi][2 * qn + 1][e] + b1[e] + (float)rr[mi][4 + e];
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
+            const int m = m0 + h * 128 + row;
+            const floatx4 v0 = stg[row * 64 + ((2 * k8) ^ (row & 7))];
+            const floatx4 v1 = stg[row * 64 + ((2 * k8 + 1) ^ (row & 7))];
             half8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + co) * 2) = o;
+            for (int e = 0; e < 4; ++e) {
+                float a = v0[e] + (float)rr[i][e], b = v1[e] + (float)rr[i][4 + e];
+                if (p.relu) {
+                    a = a > 0.f ? a : 0.f;
+                    b = b > 0.f ? b : 0.f;
+                }
+                o[e] = (_Float16)a;
+                o[4 + e] = (_Float16)b;
+            }
+            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
         }
+        if (h == 0) __syncthreads();      // staging memory is rewritten by the next half
     }
 }
 

@@ -184,7 +184,7 @@ class FRCNN:
         ms = (C.c_double * 4)()
         fl = (C.c_double * 4)()
         L.call("vk_get_kernel_timing", self._h, n, ms, fl, int(reset))
-        names = ("conv_f16_bn128", "conv_f16_bn64", "conv_f16_f32out", "other")
+        names = ("conv_mfma256", "conv_mfma_f16", "conv_mfma_f16_f32out", "other")
         return {k: {"launches": int(n[i]), "ms": float(ms[i]), "flops": float(fl[i])} for i, k in enumerate(names)}
 
     def get_stage(self, name):
