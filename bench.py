@@ -28,6 +28,20 @@ def conv_gflop_per_image(R):
     return 292.4 + 40.0 + 5.857 * R + 0.03554 * R
 
 
+def pmc_traffic(batch, proposals):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent or for another workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("batch") == batch and d.get("proposals") == proposals:
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, sd, R, det, seed):
     """The oracle (CPU restatement of the reference path, torch CPU ops, all host cores) on ONE image."""
     import torch
@@ -125,7 +139,9 @@ def main():
                                    f"through the Res5 head, max {a.detections} detections/img, seeded synthetic weights",
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(B, a.proposals),
+                         "alg_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
+                         "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "kernel": "conv_mfma256_kernel (256x256 LDS-ring implicit-GEMM conv, f16 in / f32 acc; all launches of the timed region)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
                          "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals), 1),

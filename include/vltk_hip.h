@@ -114,7 +114,7 @@ int vk_load_weights(vk_handle *h, const char *name, const void *host_ptr,
 int vk_finalize(vk_handle *h);
 int vk_destroy(vk_handle *h);
 
-/* Tunables.  "head_chunk": RoIs per Res5-head chunk (0 = all RoIs in one pass; default 1024 or
+/* Tunables.  "head_chunk": RoIs per Res5-head chunk (0 = all RoIs in one pass; default 9600 or
  * the VK_HEAD_CHUNK environment variable).  Results do not depend on it. */
 int vk_set_option(vk_handle *h, const char *key, int value);
 
@@ -156,10 +156,11 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
  * every launch; read after the forward's own end-of-call synchronisation, accumulated until reset).
  * bucket 0: conv_mfma256_kernel (256x256 LDS-ring tile; the dominant kernel)   1: conv_mfma_kernel f16->f16 (128x{64,128} tile)
  * bucket 2: conv_mfma_kernel f16->f32 out (RPN heads, predictor GEMMs)          3: f32 strict-mode convs / stem
- * launches[4], ms[4], flops[4] (algorithmic 2*M*Cout*K of the launches, doubles). */
+ * launches[4], ms[4], flops[4] (algorithmic 2*M*Cout*K of the launches), bytes[4] (algorithmic HBM bytes:
+ * input + output (+ residual) + weights, each once). */
 #define VK_NUM_KERNEL_BUCKETS 4
 int vk_enable_kernel_timing(vk_handle *h, int enable);
-int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, int reset);
+int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 
 /* ---- stage-level entry points (tests, micro-benchmarks) -------------------
  * All pointers are device pointers unless marked host.                      */

@@ -80,7 +80,7 @@ SIGNATURES = {
     "vk_enable_stage_timing": (_I, [_P, _I]),
     "vk_get_stage_timing": (_I, [_P, C.POINTER(_F)]),
     "vk_enable_kernel_timing": (_I, [_P, _I]),
-    "vk_get_kernel_timing": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D), _I]),
+    "vk_get_kernel_timing": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), _I]),
     "vk_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "vk_packed_cout": (_I, [_I]),
     "vk_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -46,6 +46,7 @@ struct ConvK {
     int relu;
     int m_tiles, n_tiles;
     double alg_flops;    // 2 * M * Cout * (kh*kw*Cin): host-side bookkeeping only
+    double alg_bytes;    // input + output (+ residual) + weights, each once
 };
 
 template <typename T>
@@ -323,7 +324,7 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         int bucket = 3;
         if (sizeof(T) == 2 && !STEM) bucket = sizeof(OutT) == 4 ? 2 : 1;
-        tm->recs.push_back({bucket, k.alg_flops, e0, e1, k.M, k.cout8, k.cin_bytes / (int)sizeof(T), k.ktiles / k.kt_per_tap, k.stride});
+        tm->recs.push_back({bucket, k.alg_flops, e0, e1, k.M, k.cout8, k.cin_bytes / (int)sizeof(T), k.ktiles / k.kt_per_tap, k.stride, k.alg_bytes});
     }
     return VK_OK;
 }
@@ -369,6 +370,8 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     }
     k.wrow_bytes = k.ktiles * CONV_KTILE_BYTES;
     k.alg_flops = 2.0 * (double)k.M * a.Cout * (a.stem ? 147.0 : (double)a.kh * a.kw * a.Cin);
+    k.alg_bytes = (double)a.N * a.H * a.W * a.Cin * es + (double)k.M * a.Cout * (dtype_size(a.out_dt) + (a.res ? es : 0)) +
+                  (double)a.Cout * a.kh * a.kw * a.Cin * es;
     k.m_tiles = ceil_div(k.M, CONV_BM);
     const bool narrow = a.Cout <= 64 || a.stem;
     k.n_tiles = ceil_div(a.Cout, narrow ? 64 : 128);

@@ -296,8 +296,21 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     // wave covers 2 rows x 512 B = 8 whole 128-B lines.
     asm volatile("s_barrier" ::: "memory");          // every wave has finished reading its fragments
     floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
+    // Residual loads are issued a phase ahead of their use (half 0 before the staging writes, half 1
+    // before half 0 is written out) and the barriers are raw (lgkmcnt only), so the HBM latency of one
+    // half hides behind the LDS work of the other instead of adding up.
+    auto load_res = [&](int h, half8 (&rr)[8]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
+            const int m = min(m0 + h * 128 + row, p.M - 1);
+            if (p.res)
+                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
+            else
+                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto stage_half = [&](int h) {
         if (wr == h) {
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn) {
@@ -313,17 +326,8 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
                 }
             }
         }
-        __syncthreads();
-        half8 rr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
-            const int m = min(m0 + h * 128 + row, p.M - 1);
-            if (p.res)
-                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
-            else
-                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+    };
+    auto write_half = [&](int h, const half8 (&rr)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
@@ -343,8 +347,19 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
             }
             if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
         }
-        if (h == 0) __syncthreads();      // staging memory is rewritten by the next half
-    }
+    };
+#define VK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    half8 r0[8], r1[8];
+    load_res(0, r0);
+    stage_half(0);
+    VK_LDS_BARRIER();
+    load_res(1, r1);
+    write_half(0, r0);
+    VK_LDS_BARRIER();
+    stage_half(1);
+    VK_LDS_BARRIER();
+    write_half(1, r1);
+#undef VK_LDS_BARRIER
 }
 
 bool conv256_eligible(const ConvArgs &a) {
@@ -420,7 +435,9 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride});
+        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride,
+                            2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) +
+                                   (double)a.Cout * a.kh * a.kw * a.Cin)});
     }
     return VK_OK;
 }

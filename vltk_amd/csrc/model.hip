@@ -41,6 +41,7 @@ void KernelTimer::collect() {
             launches[r.bucket] += 1;
             ms[r.bucket] += t;
             flops[r.bucket] += r.flops;
+            bytes[r.bucket] += r.bytes;
         }
     }
     if (lf) fclose(lf);
@@ -107,7 +108,7 @@ struct vk_handle {
     // arena
     char *arena = nullptr;
     size_t arena_bytes = 0;
-    int head_chunk = 1024;                           // RoIs per Res5 chunk (vk_set_option "head_chunk")
+    int head_chunk = 9600;                           // RoIs per Res5 chunk (vk_set_option "head_chunk")
 
     // stage bookkeeping of the last forward
     struct Stage {
@@ -969,14 +970,16 @@ int vk_enable_kernel_timing(vk_handle *h, int enable) {
     return VK_OK;
 }
 
-int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, int reset) {
-    VK_REQUIRE(h && launches && ms && flops, VK_EINVAL, "null argument");
+int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset) {
+    VK_REQUIRE(h && launches && ms && flops && bytes, VK_EINVAL, "null argument");
     VK_REQUIRE(h->ktimer, VK_EINVAL, "kernel timing is not enabled");
     for (int i = 0; i < VK_NUM_KERNEL_BUCKETS; ++i) {
         launches[i] = h->ktimer->launches[i];
         ms[i] = h->ktimer->ms[i];
         flops[i] = h->ktimer->flops[i];
+        bytes[i] = h->ktimer->bytes[i];
         if (reset) {
+            h->ktimer->bytes[i] = 0;
             h->ktimer->launches[i] = 0;
             h->ktimer->ms[i] = 0;
             h->ktimer->flops[i] = 0;

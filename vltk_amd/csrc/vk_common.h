@@ -79,6 +79,7 @@ struct KernelTimer {
         double flops;
         hipEvent_t e0, e1;
         int M, cout, cin, k, stride;
+        double bytes;
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -86,6 +87,7 @@ struct KernelTimer {
     int64_t launches[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
     double ms[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
     double flops[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
+    double bytes[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};   // algorithmic: input + output (+ residual) + weights, once each
     hipEvent_t get();
     void collect();   // after the stream has been synchronised
     ~KernelTimer();

@@ -183,9 +183,11 @@ class FRCNN:
         n = (C.c_int64 * 4)()
         ms = (C.c_double * 4)()
         fl = (C.c_double * 4)()
-        L.call("vk_get_kernel_timing", self._h, n, ms, fl, int(reset))
+        by = (C.c_double * 4)()
+        L.call("vk_get_kernel_timing", self._h, n, ms, fl, by, int(reset))
         names = ("conv_mfma256", "conv_mfma_f16", "conv_mfma_f16_f32out", "other")
-        return {k: {"launches": int(n[i]), "ms": float(ms[i]), "flops": float(fl[i])} for i, k in enumerate(names)}
+        return {k: {"launches": int(n[i]), "ms": float(ms[i]), "flops": float(fl[i]), "bytes": float(by[i])}
+                for i, k in enumerate(names)}
 
     def get_stage(self, name):
         """Intermediate tensor of the last forward as a torch tensor (a copy)."""
