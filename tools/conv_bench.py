@@ -30,6 +30,7 @@ SHAPES = {
 
 
 def main():
+    variants = [v for v in os.environ.get("VARIANTS", "").split(",") if v]   # e.g. VARIANTS=0,4,8: VK_CONV256_DBG values, interleaved rounds
     names = sys.argv[1:] or list(SHAPES)
     iters = int(os.environ.get("ITERS", "10"))
     g = np.random.Generator(np.random.PCG64(0))
@@ -46,6 +47,25 @@ def main():
         def run():
             L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad,
                    dil, 1, L.VK_F16, L.VK_F16, G.stream())
+        M = N * Ho * Wo
+        if variants:      # interleaved A/B rounds in ONE process on ONE device (cdna guide rule 24)
+            res_ms = {v: [] for v in variants}
+            for rnd in range(int(os.environ.get("ROUNDS", "5"))):
+                for v in variants:
+                    os.environ["VK_CONV256_DBG"] = v
+                    run()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res_ms[v].append(e0.elapsed_time(e1) / iters)
+            fl = 2.0 * M * cout * cin * k * k
+            print(name, " ".join(f"v{v}: med {np.median(t) * 1e3:.1f} us min {min(t) * 1e3:.1f} us "
+                                 f"({fl / np.median(t) / 1e9:.0f} TF)" for v, t in res_ms.items()), flush=True)
+            continue
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -56,7 +76,6 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        M = N * Ho * Wo
         fl = 2.0 * M * cout * cin * k * k
         by = 2.0 * (M * cin + M * cout * (2 if use_res else 1) + cout * cin * k * k)
         print(f"{name:12s} M={M:8d} cout={cout:5d} K={cin * k * k:5d} {ms * 1e3:9.1f} us {fl / ms / 1e9:8.1f} TFLOP/s "

@@ -54,8 +54,10 @@ constexpr int R_SMEM = R_NSLOT * R_SLOT;     // 128 KiB
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-// DBG != 0 are timing-only diagnostic builds (wrong results): 1 = no LDS-DMA in the steady state,
-// 2 = no pixel-row fragment reads, 3 = both.  Selected with VK_CONV256_DBG; never used by the product path.
+// DBG != 0 are diagnostic / A-B builds selected with VK_CONV256_DBG (never used by the product path):
+// 1 = no LDS-DMA in the steady state, 2 = no pixel-row fragment reads, 3 = both (timing only, WRONG results);
+// 4 = static s_setprio(1) for waves 4-7 (no effect measured), 8 = WITHOUT the s_setprio pair around each
+// 4-MFMA group (the pair is worth +1.3 % median, interleaved A/B in one process on one device).
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,6 +141,9 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         w_addr[par] = R_XB + wrow * R_ROWB + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
     }
 
+    if constexpr (DBG & 4) {   // experiment: static priority for the younger half (guide T5 static form)
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
     floatx4 acc[8][4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
@@ -168,8 +173,12 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     } while (0)
 #define VK_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
 #define VK_MMA_ROW(MI, XR, WF)                                                                       \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                                   \
-        __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0)
+    do {                                                                                             \
+        if constexpr (!(DBG & 8)) __builtin_amdgcn_s_setprio(1);                                     \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                               \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0);                \
+        if constexpr (!(DBG & 8)) __builtin_amdgcn_s_setprio(0);                                     \
+    } while (0)
 #define VK_READ_W(WF, so)          \
     VK_DSR(WF[0], w_a0 + so, 0);   \
     VK_DSR(WF[1], w_a1 + so, 0);   \
@@ -388,6 +397,10 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
         attr_set = true;
     }
     Conv256K k;
@@ -424,12 +437,14 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
         e1 = tm->get();
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
-    static const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
+    const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;   // re-read: lets one process A/B variants
     const dim3 grid(k.m_tiles * k.n_tiles), block(512);
     switch (dbg) {
         case 1: hipLaunchKernelGGL(conv_mfma256_kernel<1>, grid, block, R_SMEM, stream, k); break;
         case 2: hipLaunchKernelGGL(conv_mfma256_kernel<2>, grid, block, R_SMEM, stream, k); break;
         case 3: hipLaunchKernelGGL(conv_mfma256_kernel<3>, grid, block, R_SMEM, stream, k); break;
+        case 4: hipLaunchKernelGGL(conv_mfma256_kernel<4>, grid, block, R_SMEM, stream, k); break;
+        case 8: hipLaunchKernelGGL(conv_mfma256_kernel<8>, grid, block, R_SMEM, stream, k); break;
         default: hipLaunchKernelGGL(conv_mfma256_kernel<0>, grid, block, R_SMEM, stream, k);
     }
     VK_CHECK_HIP(hipGetLastError());
