@@ -52,7 +52,9 @@ def main():
             res_ms = {v: [] for v in variants}
             for rnd in range(int(os.environ.get("ROUNDS", "5"))):
                 for v in variants:
-                    os.environ["VK_CONV256_DBG"] = v
+                    # a variant is "<dbg>" or "<kernel><dbg>", e.g. "0", "b0", "b1"
+                    os.environ["VK_CONV256_KERNEL"] = v[0] if v[0] in "ab" else "a"
+                    os.environ["VK_CONV256_DBG"] = v.lstrip("ab") or "0"
                     run()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -330,7 +330,11 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
-    if (conv256_eligible(a)) return launch_conv256(a, stream);
+    if (conv256_eligible(a)) {
+        const char *v = getenv("VK_CONV256_KERNEL");      // "a" | "b": A/B switch, re-read per call
+        if (v && v[0] == 'b' && conv256b_eligible(a)) return launch_conv256b(a, stream);
+        return launch_conv256(a, stream);
+    }
     const int es = (int)dtype_size(a.dt);
     VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32, VK_EINVAL, "conv: dtype must be f16 or f32");
     VK_REQUIRE(a.out_dt == a.dt || a.out_dt == VK_F32, VK_EINVAL, "conv: out dtype must equal dtype or be f32");
