@@ -197,6 +197,14 @@ int vk_stem(const float *x, int N, int H, int W, const void *w_packed, const flo
 size_t vk_stem_workspace_bytes(int N, int H, int W, int cout, vk_dtype dt);
 void vk_stem_out_hw(int H, int W, int caffe_maxpool, int *Ho, int *Wo);
 
+/* Image pre-processing  <- ResizeShortestEdge + Preprocess, vltk/legacy/processing.py:29-150:
+ * per image bilinear resize (align_corners=False) of a float HWC (BGR 0-255) device image to new_hw, (x-mean)/std,
+ * pad with pad_value to [N,3,Hmax,Wmax] f32 NCHW.  raw_dev_ptrs_host: host array of N device pointers;
+ * raw_hw_host / new_hw_host: host [N,2] (h, w); the resize size rule itself is host logic (vltk_amd/preprocess.py). */
+int vk_preprocess(const float *const *raw_dev_ptrs_host, const int32_t *raw_hw_host, const int32_t *new_hw_host,
+                  int N, int Hmax, int Wmax, const float *mean3_host, const float *std3_host, float pad_value,
+                  float *out_nchw_dev, void *stream);
+
 /* max-pool 3x3 s2 (ceil_mode pad 0, or pad 1)  <- frcnn.py:875-878 */
 int vk_maxpool3x3s2(const void *x, int N, int H, int W, int C, int caffe, void *y, vk_dtype dt, void *stream);
 

@@ -237,3 +237,33 @@ def test_full_size_properties():
     pad2 = m.forward_padded()
     for k in pad1:
         assert torch.equal(pad1[k], pad2[k].flip(0)), k
+
+
+def test_preprocess_extract_chain(setup, tmp_path):
+    """N2 -> hot path -> N1: raw float HWC images -> GPU Preprocess -> FRCNN -> Arrow file readable like the reference's."""
+    from vltk_amd.extraction import extract, load_extraction
+    from vltk_amd.preprocess import Preprocess
+    from vltk_amd.config import Config, vg_c4_config_dict
+    cfg, sd, _, _ = setup
+    d = vg_c4_config_dict(post_nms_topk=int(cfg.RPN.POST_NMS_TOPK_TEST), detections=int(cfg.MAX_DETECTIONS))
+    d["input"]["min_size_test"], d["input"]["max_size_test"] = 160, 224
+    pcfg = Config(d)
+    g = np.random.Generator(np.random.PCG64(5))
+    raws = [torch.from_numpy(g.uniform(0, 255, (h, w, 3)).astype(np.float32)) for h, w in ((120, 150), (200, 140), (90, 160))]
+    ids, images, sizes, scales_yx = Preprocess(pcfg)(raws, ["a1", "b2", "c3"])
+    assert images.shape[0] == 3 and images.shape[2] <= 224 and images.shape[3] <= 224
+    model = FRCNN(cfg).load_state_dict(sd).eval()
+    model.roi_outputs.nms_thresh = [0.3, 1.0]
+    entries = [{"image": images[i], "size": sizes[i], "wh_scale": torch.tensor([1.0 / scales_yx[i, 1], 1.0 / scales_yx[i, 0]]),
+                "imgid": ids[i]} for i in range(3)]
+    path = extract(model, entries, str(tmp_path / "synthetic" / "frcnn"), split="train", dataset="synthetic", batch_size=2)
+    table, meta = load_extraction(path)
+    D = int(cfg.MAX_DETECTIONS)
+    assert table.num_rows == 3 and meta["img_to_row_map"] == {"a1": 0, "b2": 1, "c3": 2}
+    row = table.slice(1, 1).to_pylist()[0]
+    feats = np.asarray(row["features"], dtype=np.float32)
+    assert feats.shape == (D, 2048) and np.isfinite(feats).all() and (feats >= 0).all() and feats.max() > 0
+    # the written row equals a direct forward of the same image (batching does not change results)
+    out = model(images[1:2], sizes[1:2])
+    np.testing.assert_array_equal(feats[: int(out["preds_per_image"][0])], out["roi_features"][0].cpu().numpy())
+    assert len(row["object_ids"]) == D and len(row["box"]) == D

@@ -286,9 +286,50 @@ def e2e(ref, name, n, h, w, shapes, post_topk, det, seed, depth=101):
           "min cls margin %.2e" % out["cls_margin"].min())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--preprocess" not in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = load_reference()
     kat_ops(ref)
     e2e(ref, "e2e_r101_small", n=2, h=160, w=224, shapes=[[160, 224], [144, 200]], post_topk=30, det=12, seed=1234)
+
+
+# ---------------------------------------------------------------------------
+def preprocess_golden():
+    """Golden vectors of the reference's legacy `Preprocess` (vltk/legacy/processing.py:29-150):
+    float HWC (BGR 0-255) tensors -> shortest-edge bilinear resize -> (x - mean)/std -> zero-pad to the batch max."""
+    pk = types.ModuleType("vltk.legacy")
+    pk.__path__ = []
+    tc = types.ModuleType("vltk.legacy.transformers_compat")
+    tc.img_tensorize = lambda *a, **k: None
+    sys.modules.update({"vltk.legacy": pk, "vltk.legacy.transformers_compat": tc})
+    spec = importlib.util.spec_from_file_location("vltk.legacy.processing", "/root/reference/vltk/legacy/processing.py")
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "vltk.legacy"
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, (mn, mx), shapes in (("small", (48, 80), [(37, 53), (60, 41), (50, 50)]),
+                                  ("capped", (64, 96), [(30, 90), (100, 20)]),
+                                  ("vg", (800, 1333), [(375, 500)])):
+        d = vg_c4_config_dict()
+        d["input"]["min_size_test"], d["input"]["max_size_test"] = mn, mx
+        pre = mod.Preprocess(Config(d))
+        # raw images are NOT stored: tests regenerate them from (seed 7700 + index, shape)
+        raws = [torch.from_numpy(np.random.Generator(np.random.PCG64(7700 + i)).uniform(0, 255, (h, w, 3)).astype(np.float32))
+                for i, (h, w) in enumerate(shapes)]
+        out[f"{tag}/raw_shapes"] = np.asarray(shapes)
+        ids, images, sizes, scales = pre([r.clone() for r in raws], list(range(len(raws))))
+        out[f"{tag}/minmax"] = np.asarray([mn, mx])
+        if tag == "vg":      # full-size case: keep a checksum + a crop, not 12 MB
+            out[f"{tag}/images_crop"] = np_(images[:, :, 100:164, 200:264])
+            out[f"{tag}/images_sum"] = np_(images.double().sum(dim=(2, 3)).float())
+            out[f"{tag}/images_shape"] = np.asarray(images.shape)
+        else:
+            out[f"{tag}/images"] = np_(images)
+        out[f"{tag}/sizes"], out[f"{tag}/scales_yx"] = np_(sizes), np_(scales)
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **out)
+    print("preprocess.npz:", {k: v.shape for k, v in out.items() if k.endswith(("images", "sizes"))})
+
+
+if __name__ == "__main__" and "--preprocess" in sys.argv:
+    preprocess_golden()

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vk_stem": (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _P, _I, _P, _SZ, _P]),
     "vk_stem_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "vk_stem_out_hw": (None, [_I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "vk_preprocess": (_I, [_P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _F, _P, _P]),
     "vk_maxpool3x3s2": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "vk_rpn_workspace_bytes": (_SZ, [_I, _I, _I]),
     "vk_rpn_proposals": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _F, _P, C.POINTER(_F), _F, _D, _I, _I,
