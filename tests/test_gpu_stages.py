@@ -49,6 +49,13 @@ CONV_CASES = [
     ("ring_3x3", 2, 25, 31, 64, 256, 3, 1, 1, 1, False, True),
     ("ring_3x3_dil2", 7, 14, 14, 128, 256, 3, 1, 2, 2, False, True),
     ("ring_1x1_s2", 2, 47, 51, 256, 512, 1, 2, 0, 1, False, False),
+    # LDS-panel 3x3 kernel (stride 1, pad == dil, Cin >= 128, Cout % 256 == 0): halo 64 (PP=3) and 128 (PP=4),
+    # RoI-shaped maps whose taps cross image borders inside a tile, image-count not a multiple of the tile
+    ("panel_head", 9, 14, 14, 128, 256, 3, 1, 2, 2, False, True),
+    ("panel_head_res", 11, 14, 14, 256, 512, 3, 1, 2, 2, True, True),
+    ("panel_d1", 3, 20, 31, 128, 256, 3, 1, 1, 1, False, True),
+    ("panel_wide", 1, 18, 84, 192, 256, 3, 1, 1, 1, False, False),
+    ("panel_wide_d1", 2, 30, 100, 128, 256, 3, 1, 1, 1, True, True),
 ]
 
 

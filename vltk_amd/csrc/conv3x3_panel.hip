@@ -1,0 +1,455 @@
+// 3x3 convolution (stride 1, pad == dilation) with an LDS-RESIDENT INPUT PANEL: the conv-native kernel
+// for the layers where an im2col GEMM wastes the most bytes (Res5 conv2 with dilation 2, res4 conv2, RPN 3x3).
+//
+// Why: the 256x256 im2col ring kernel (conv_mfma256.hip) is bound by the supply of distinct cache lines
+// through the CU's L1-miss path (~15 B/clk/CU) and an im2col GEMM fetches every input pixel
+// NINE times (once per tap).  Here K is walked channel-stage-major / tap-minor: the 32-channel slab of the
+// tile's pixels PLUS HALO (all pixels any tap can touch) is brought into LDS ONCE per channel stage and the
+// nine taps read it at nine row shifts; only the weights stream per (tap, stage).  Bytes through the CU per
+// 32-channel stage: 9 x 16 KiB weights + ~24-32 KiB panel  vs  9 x 32 KiB  (-40...-45 %).
+//
+//   * LDS: 2 panel buffers of PP*128 rows x 64 B (PP = 3 or 4: halo 64 / 128 rows >= dil*(W+1)) + a ring of
+//     6 weight slots (256 channels x 64 B): 144 / 160 KiB.  Same 64-B-row XOR swizzle as the ring kernel,
+//     applied on the DMA source address; the fragment address is recomputed per tap (the shift moves the key).
+//   * a tap is a UNIFORM row shift ((kh-1)*W + (kw-1))*dil of the fragment reads; pixels whose tap falls outside
+//     the image (or into the neighbouring image, or rows >= M) are zeroed in registers from a precomputed
+//     72-bit per-lane validity mask (4 v_cndmask per fragment).
+//   * per step (one tap of one stage) = 32 MFMAs per wave, one raw barrier, 2 weight DMA pieces per wave,
+//     plus one panel piece of the NEXT channel stage on the first PP taps; hand-issued ds_read_b128 with
+//     counted lgkmcnt, counted vmcnt (the count depends only on the tap index: compile-time).
+//   * same per-wave geometry (2x4 waves, 128x64 per wave, 16x16x32 f16 MFMA) and the same LDS-staged
+//     whole-row epilogue as conv_mfma256.hip.
+#include <type_traits>
+
+#include "vk_common.h"
+
+namespace vk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+struct PanelK {
+    const char *x;
+    const char *w;
+    const float *bias;
+    const char *res;
+    char *y;
+    int H, W, HW, M;
+    int cin_bytes, ldy;
+    int dil;
+    int cstages;              // Cin / 32 (even)
+    int wrow_bytes;           // 9 * Cin * 2
+    int relu;
+    int m_tiles, n_tiles;
+};
+
+constexpr int P_NW = 6;                     // weight ring slots
+constexpr int P_WSLOT = 256 * 64;           // 16 KiB
+
+#define VKP_GLDS16(gptr, lptr)                                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// panel pieces issued in the window of P_NW-2 steps before tap J (taps of the previous stage when negative)
+template <int J, int PP>
+constexpr int panel_in_window() {
+    int c = 0;
+    for (int d = 1; d <= P_NW - 2; ++d) {
+        int t = ((J - d) % 9 + 9) % 9;
+        if (t < PP) ++c;
+    }
+    return c;
+}
+// weight pieces (x2) issued in that window during the LAST channel stage (its taps >= 3 issue nothing)
+template <int J>
+constexpr int last_w_in_window() {
+    int c = 0;
+    for (int d = 1; d <= P_NW - 2; ++d) {
+        int t = J - d;                     // < 0: previous stage, always issues
+        if (t < 0 || t + P_NW < 9) ++c;
+    }
+    return 2 * c;
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    static_assert(N >= 0 && N <= 15, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// DBG: timing-only diagnostic builds (VK_CONV256_DBG): 1 = no tap-validity masking (WRONG results)
+template <int PP, int DBG>
+__global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PROWS = PP * 128;               // panel rows
+    constexpr int HALO = (PROWS - 256) / 2;       // 64 or 128
+    constexpr int PBYTES = PROWS * 64;
+    constexpr int WBASE = 2 * PBYTES;
+
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int n_tile = t_ % p.n_tiles, m_tile = t_ / p.n_tiles;
+    const int m0 = m_tile * 256, n0 = n_tile * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int g = lane >> 4, j = lane & 15;
+
+    // ---- per-lane tap validity of its 8 fragment pixels (rows wr*128 + mi*16 + j): bit (tap*8 + mi) ----
+    unsigned vm0 = 0, vm1 = 0, vm2 = 0;           // taps 0-3 | 4-7 | 8
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wr * 128 + mi * 16 + j;
+        if (m < p.M) {
+            const int n_img = m / p.HW;
+            const int rem = m - n_img * p.HW;
+            const int ho = rem / p.W, wo = rem - ho * p.W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int hi = ho + (tap / 3 - 1) * p.dil, wi = wo + (tap % 3 - 1) * p.dil;
+                const unsigned ok = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? 1u : 0u;
+                if (tap < 4)
+                    vm0 |= ok << (tap * 8 + mi);
+                else if (tap < 8)
+                    vm1 |= ok << ((tap - 4) * 8 + mi);
+                else
+                    vm2 |= ok << mi;
+            }
+        }
+    }
+
+    // ---- LDS-DMA source state ----
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
+    const int pm_first = m0 - HALO + wave * 16 + lrow;        // pixel of panel row (piece q): + q*128
+    // 32-bit byte offsets from the (uniform) tensor bases: the launcher checks both tensors are < 4 GiB
+    const unsigned wsrc0 = (unsigned)(n0 + wave * 32 + lrow) * (unsigned)p.wrow_bytes + lchunk * 16;   // piece i: + i*16 rows
+    const unsigned wstep = 16u * p.wrow_bytes;
+    auto req_panel = [&](int cs, int piece) {                 // rows (piece*8 + wave)*16 .. +15 of panel(cs)
+        int pf = pm_first;
+        asm volatile("" : "+v"(pf));                           // opaque (see x_addr_of)
+        // rows outside [0, M) are only ever read by taps the validity mask zeroes: any finite-or-not data
+        // will do there, so clamp to a real row instead of branching to a zero page
+        const int m = min(max(pf + piece * 128, 0), p.M - 1);
+        const unsigned off = (unsigned)m * (unsigned)p.cin_bytes + cs * 64 + lchunk * 16;
+        VKP_GLDS16(p.x + off, smem + (cs & 1) * PBYTES + (piece * 8 + wave) * 1024);
+    };
+    auto req_w = [&](int slot, int cs, int tap, int i) {      // rows (wave*2+i)*16 .. +15 of weight slot `slot`
+        const unsigned koff = (unsigned)(tap * p.cstages + cs) * 64;  // K layout = (tap, channel): tap*Cin*2 + cs*64 bytes
+        unsigned wb_ = wsrc0;
+        asm volatile("" : "+v"(wb_));                          // opaque (see x_addr_of)
+        VKP_GLDS16(p.w + (wb_ + i * wstep + koff), smem + WBASE + slot * P_WSLOT + (wave * 2 + i) * 1024);
+    };
+
+    // ---- fragment addressing ----
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    unsigned w_a[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int wrow = wc * 64 + (j >> 2) * 8 + par * 4 + (j & 3);
+        w_a[par] = lds0 + WBASE + wrow * 64 + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
+    }
+    const int jbase = HALO + wr * 128 + j;                    // panel row of fragment pixel mi = 0 at zero shift
+    auto x_addr_of = [&](int parity, int tap) -> unsigned {   // byte address of fragment row mi = 0 (panel `parity`, tap)
+        const int shift = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.dil;
+        int jb = jbase;
+        asm volatile("" : "+v"(jb));                           // opaque: the 18 (panel, tap) addresses must not be hoisted
+        const int rb = jb + shift;                             // >= 0: HALO >= dil*(W+1)
+        return lds0 + parity * PBYTES + (rb << 6) + ((g ^ ((-(rb >> 2)) & 3)) << 4);
+    };
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 wa[4], wb[4], xw[4];
+    const int CS = p.cstages;
+
+#define VKP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define VKP_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
+#define VKP_SB() __builtin_amdgcn_sched_barrier(0)
+    // zero a fragment whose pixel is outside the image for this tap (4 v_cndmask), then 4 MFMAs
+#define VKP_MMA_ROW(MI, XR, WF, TM)                                                                  \
+    do {                                                                                             \
+        if constexpr (!(DBG & 1)) {                                                                  \
+            uintx4 u_ = __builtin_bit_cast(uintx4, XR);                                              \
+            const bool v_ = ((TM) >> (MI)) & 1u;                                                     \
+            u_[0] = v_ ? u_[0] : 0u;                                                                 \
+            u_[1] = v_ ? u_[1] : 0u;                                                                 \
+            u_[2] = v_ ? u_[2] : 0u;                                                                 \
+            u_[3] = v_ ? u_[3] : 0u;                                                                 \
+            XR = __builtin_bit_cast(half8, u_);                                                      \
+        }                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                               \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0);                \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+    } while (0)
+    // (the slot addresses are recomputed in the loop from opaque copies: hipcc would otherwise keep all
+    //  2 x 6 slot addresses in registers)
+#define VKP_READ_W(WF, so)                              \
+    do {                                                \
+        unsigned a0_ = w_a[0], a1_ = w_a[1];            \
+        asm volatile("" : "+v"(a0_), "+v"(a1_));        \
+        a0_ += so;                                      \
+        a1_ += so;                                      \
+        VKP_DSR(WF[0], a0_, 0);                         \
+        VKP_DSR(WF[1], a1_, 0);                         \
+        VKP_DSR(WF[2], a0_, 2048);                      \
+        VKP_DSR(WF[3], a1_, 2048);                      \
+    } while (0)
+
+    // One step = tap J of channel stage cs (global step t = 9*cs + J).  LAST: cs is the final stage
+    // (no panel prefetch, weight requests stop when t + 6 >= 9*CS, no step after tap 8).
+    // ODD = parity of cs (stages run in pairs, so it is known at compile time): panel buffer = ODD, and the
+    // weight slot of step t = 9*cs + J is (3*ODD + J) % 6.
+    auto step = [&](auto last_c, auto odd_c, auto j_c, int cs, unsigned xa, unsigned &xa_next, const half8 (&wcur)[4],
+                    half8 (&wnext)[4]) {
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr int ODD = decltype(odd_c)::value ? 1 : 0;
+        constexpr int J = decltype(j_c)::value;
+        constexpr int SLOT = (3 * ODD + J) % P_NW;            // == t % 6; also the slot of step t + 6
+        // opaque copy of the mask word BEFORE the shift: otherwise hipcc hoists either the 72 (tap, row-tile)
+        // lane masks (SGPR pairs) or the 9 shifted words out of the loop and spills them
+        unsigned tw = J < 4 ? vm0 : (J < 8 ? vm1 : vm2);
+        asm volatile("" : "+v"(tw));
+        const unsigned tm = tw >> ((J & 3) * 8);
+        constexpr bool has_next = !(LAST && J == 8);
+        constexpr bool issue_w = !LAST || (J + P_NW < 9);
+        constexpr bool issue_p = !LAST && (J < PP);
+        // address of the next step's fragments (next tap; next stage's panel after tap 8)
+        if constexpr (has_next) xa_next = (J == 8) ? x_addr_of(1 - ODD, 0) : x_addr_of(ODD, J + 1);
+        VKP_DSR(xw[3], xa, 3072); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(0, xw[0], wcur, tm); VKP_SB();
+        VKP_DSR(xw[0], xa, 4096); VKP_WAIT3(xw[1]); VKP_SB(); VKP_MMA_ROW(1, xw[1], wcur, tm); VKP_SB();
+        VKP_DSR(xw[1], xa, 5120); VKP_WAIT3(xw[2]); VKP_SB(); VKP_MMA_ROW(2, xw[2], wcur, tm); VKP_SB();
+        VKP_DSR(xw[2], xa, 6144); VKP_WAIT3(xw[3]); VKP_SB(); VKP_MMA_ROW(3, xw[3], wcur, tm); VKP_SB();
+        VKP_DSR(xw[3], xa, 7168); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+        if constexpr (has_next) {
+            // all reads of this step are issued.  vmcnt: everything older than the pieces issued in the last
+            // P_NW-2 steps has landed = weights of step t+1 (and, before tap 0, the next stage's panel);
+            // lgkmcnt(0) + barrier: weight slot (t % 6) is free for step t+6, the other panel buffer is free
+            // once the stage ends.
+            constexpr int OUT = LAST ? last_w_in_window<J>() : 2 * (P_NW - 2) + panel_in_window<J, PP>();
+            vm_wait<OUT>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+            VKP_SB();
+            constexpr unsigned so = (unsigned)((SLOT + 1) % P_NW) * P_WSLOT;
+            VKP_READ_W(wnext, so);
+            VKP_DSR(xw[0], xa_next, 0);
+            VKP_SB();
+            VKP_MMA_ROW(5, xw[1], wcur, tm);
+            VKP_SB();
+            if constexpr (issue_p) req_panel(cs + 1, J);
+            if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 0);
+            VKP_DSR(xw[1], xa_next, 1024);
+            VKP_SB();
+            VKP_MMA_ROW(6, xw[2], wcur, tm);
+            VKP_SB();
+            if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 1);
+            VKP_DSR(xw[2], xa_next, 2048);
+            VKP_SB();
+            VKP_MMA_ROW(7, xw[3], wcur, tm);
+            VKP_SB();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
+            VKP_SB();
+            VKP_MMA_ROW(5, xw[1], wcur, tm);
+            VKP_MMA_ROW(6, xw[2], wcur, tm);
+            VKP_MMA_ROW(7, xw[3], wcur, tm);
+        }
+    };
+    // nine taps of one stage; the weight-fragment sets alternate, so a stage flips their roles: `flip` says
+    // which set is current at tap 0
+#define VKP_TAP(LASTC, JJ, CUR, NXT)                                                                 \
+    step(LASTC, flip_c, std::integral_constant<int, JJ>{}, cs, xa, xan, CUR, NXT);                    \
+    xa = xan;
+    auto stage9 = [&](auto last_c, auto flip_c, int cs, unsigned &xa) {
+        constexpr bool FLIP = decltype(flip_c)::value;
+        unsigned xan = 0;
+        if constexpr (!FLIP) {
+            VKP_TAP(last_c, 0, wa, wb) VKP_TAP(last_c, 1, wb, wa) VKP_TAP(last_c, 2, wa, wb) VKP_TAP(last_c, 3, wb, wa)
+            VKP_TAP(last_c, 4, wa, wb) VKP_TAP(last_c, 5, wb, wa) VKP_TAP(last_c, 6, wa, wb) VKP_TAP(last_c, 7, wb, wa)
+            VKP_TAP(last_c, 8, wa, wb)
+        } else {
+            VKP_TAP(last_c, 0, wb, wa) VKP_TAP(last_c, 1, wa, wb) VKP_TAP(last_c, 2, wb, wa) VKP_TAP(last_c, 3, wa, wb)
+            VKP_TAP(last_c, 4, wb, wa) VKP_TAP(last_c, 5, wa, wb) VKP_TAP(last_c, 6, wb, wa) VKP_TAP(last_c, 7, wa, wb)
+            VKP_TAP(last_c, 8, wb, wa)
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+
+    // ---- prologue: panel(0), weights of steps 0..5; panel(0) and weights(0) must have landed ----
+#pragma unroll
+    for (int q2 = 0; q2 < PP; ++q2) req_panel(0, q2);
+#pragma unroll
+    for (int st = 0; st < P_NW; ++st) {
+        req_w(st, 0, st, 0);
+        req_w(st, 0, st, 1);
+    }
+    vm_wait<2 * (P_NW - 1)>();
+    asm volatile("s_barrier" ::: "memory");
+    unsigned xa = x_addr_of(0, 0);
+    VKP_READ_W(wa, 0u);
+    VKP_DSR(xw[0], xa, 0);
+    VKP_DSR(xw[1], xa, 1024);
+    VKP_DSR(xw[2], xa, 2048);
+    // CS is even: stages go in pairs (the second stage of a pair starts with the fragment sets flipped)
+    int cs = 0;
+    for (; cs + 2 < CS; cs += 2) {
+        stage9(F_{}, F_{}, cs, xa);
+        stage9(F_{}, T_{}, cs + 1, xa);
+    }
+    stage9(F_{}, F_{}, cs, xa);
+    stage9(T_{}, T_{}, cs + 1, xa);
+#undef VKP_TAP
+#undef VKP_DSR
+#undef VKP_WAIT3
+#undef VKP_MMA_ROW
+#undef VKP_READ_W
+#undef VKP_SB
+
+    // ---- epilogue (as conv_mfma256.hip): + bias (+ residual)(ReLU) through LDS, whole 512-B rows ----
+    asm volatile("s_barrier" ::: "memory");
+    floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
+    auto load_res = [&](int h, half8 (&rr)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
+            const int m = min(m0 + h * 128 + row, p.M - 1);
+            if (p.res)
+                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
+            else
+                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto stage_half = [&](int h) {
+        if (wr == h) {
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                const int col = wc * 64 + qn * 32 + g * 8;
+                const floatx4 b0 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[0];
+                const floatx4 b1 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[1];
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int row = mi * 16 + j;
+                    const int c16 = col >> 2;
+                    stg[row * 64 + (c16 ^ (row & 7))] = acc[mi][2 * qn] + b0;
+                    stg[row * 64 + ((c16 + 1) ^ (row & 7))] = acc[mi][2 * qn + 1] + b1;
+                }
+            }
+        }
+    };
+    auto write_half = [&](int h, const half8 (&rr)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 512 * i, row = it >> 5, k8 = it & 31;
+            const int m = m0 + h * 128 + row;
+            const floatx4 v0 = stg[row * 64 + ((2 * k8) ^ (row & 7))];
+            const floatx4 v1 = stg[row * 64 + ((2 * k8 + 1) ^ (row & 7))];
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = v0[e] + (float)rr[i][e], b = v1[e] + (float)rr[i][4 + e];
+                if (p.relu) {
+                    a = a > 0.f ? a : 0.f;
+                    b = b > 0.f ? b : 0.f;
+                }
+                o[e] = (_Float16)a;
+                o[4 + e] = (_Float16)b;
+            }
+            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
+        }
+    };
+#define VKP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    half8 r0[8];
+    load_res(0, r0);
+    stage_half(0);
+    VKP_LDS_BARRIER();
+    write_half(0, r0);
+    load_res(1, r0);
+    VKP_LDS_BARRIER();
+    stage_half(1);
+    VKP_LDS_BARRIER();
+    write_half(1, r0);
+#undef VKP_LDS_BARRIER
+}
+
+static int panel_pp(const ConvArgs &a) {
+    const int reach = a.dil * (a.W + 1);
+    return reach <= 64 ? 3 : (reach <= 128 ? 4 : 0);
+}
+
+bool conv3x3_panel_eligible(const ConvArgs &a) {
+    const char *v = getenv("VK_CONV3X3_PANEL");          // "0" disables (A/B switch, re-read per call)
+    if (v && v[0] == '0') return false;
+    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
+    if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != a.dil) return false;
+    if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cin % 64 != 0 || a.Cin < 128) return false;
+    if (panel_pp(a) == 0) return false;
+    if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets
+    return (long)a.N * a.H * a.W >= 4 * 256;
+}
+
+int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<4, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64 + P_NW * P_WSLOT));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        attr_set = true;
+    }
+    PanelK k;
+    k.x = (const char *)a.x;
+    k.w = (const char *)a.w;
+    k.bias = a.bias;
+    k.res = (const char *)a.res;
+    k.y = (char *)a.y;
+    k.H = a.H;
+    k.W = a.W;
+    k.HW = a.H * a.W;
+    const long M = (long)a.N * a.H * a.W;
+    VK_REQUIRE(M > 0 && M < (1L << 31) - 512, VK_EINVAL, "conv3x3_panel: M=%ld out of range", M);
+    VK_REQUIRE(M * a.Cin * 2 < (1L << 32) && (long)a.Cout * 9 * a.Cin * 2 < (1L << 32), VK_EINVAL,
+               "conv3x3_panel: tensor beyond the 32-bit DMA offsets (M=%ld Cin=%d Cout=%d)", M, a.Cin, a.Cout);
+    k.M = (int)M;
+    k.cin_bytes = a.Cin * 2;
+    k.ldy = a.ldy;
+    k.dil = a.dil;
+    k.cstages = a.Cin / 32;
+    k.wrow_bytes = 9 * a.Cin * 2;
+    k.relu = a.relu;
+    k.m_tiles = ceil_div(k.M, 256);
+    k.n_tiles = a.Cout / 256;
+    KernelTimer *tm = g_timer;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (tm) {
+        e0 = tm->get();
+        e1 = tm->get();
+        VK_CHECK_HIP(hipEventRecord(e0, stream));
+    }
+    const dim3 grid(k.m_tiles * k.n_tiles), block(512);
+    const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
+    if (panel_pp(a) == 3 && dbg == 1)
+        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    else if (panel_pp(a) == 3)
+        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    else
+        hipLaunchKernelGGL((conv3x3_panel_kernel<4, 0>), grid, block, 2 * 4 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    VK_CHECK_HIP(hipGetLastError());
+    if (tm) {
+        VK_CHECK_HIP(hipEventRecord(e1, stream));
+        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * 9 * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 9, 1,
+                            2.0 * ((double)k.M * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * 9 * a.Cin)});
+    }
+    return VK_OK;
+}
+
+}  // namespace vk

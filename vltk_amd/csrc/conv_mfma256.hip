@@ -40,6 +40,7 @@ struct Conv256K {
     int cin_bytes, ldy;
     int kw, stride, pad, dil;
     int stages, st_per_tap;   // K stages of 32 channels
+    int ntaps;                // kh * kw
     int wrow_bytes;
     int relu;
     int m_tiles, n_tiles;
@@ -56,6 +57,7 @@ constexpr int R_SMEM = R_NSLOT * R_SLOT;     // 128 KiB
 
 // DBG != 0 are diagnostic / A-B builds selected with VK_CONV256_DBG (never used by the product path):
 // 1 = no LDS-DMA in the steady state, 2 = no pixel-row fragment reads, 3 = both (timing only, WRONG results);
+// 16 = taps innermost (no gain), 32 / 64 = weight / pixel DMA pieces all read ONE cached line (timing only),
 // 4 = static s_setprio(1) for waves 4-7 (no effect measured), 8 = WITHOUT the s_setprio pair around each
 // 4-MFMA group (the pair is worth +1.3 % median, interleaved A/B in one process on one device).
 template <int DBG>
@@ -111,24 +113,45 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool ok = (unsigned)(bh[i] + dh) < (unsigned)p.H && (unsigned)(bw[i] + dw) < (unsigned)p.W;
-            xsrc[i] = ok ? p.x + a_off[i] + toff : p.zero;
+            xsrc[i] = (ok && !(DBG & 64)) ? p.x + a_off[i] + toff : p.zero;   // DBG 64: every pixel piece reads one cached line
         }
         // branch-free advance of (kernel row, kernel col, channel stage): keeps the K loop one basic block
-        kc += 1;
-        const int c1 = (kc == p.st_per_tap) ? 1 : 0;
-        kc *= (1 - c1);
-        kwi += c1;
-        const int c2 = (kwi == p.kw) ? 1 : 0;
-        kwi *= (1 - c2);
-        khi += c2;
+        if constexpr (DBG & 16) {   // experiment: taps innermost (consecutive stages re-read almost the same pixel lines)
+            kwi += 1;
+            const int c1 = (kwi == p.kw) ? 1 : 0;
+            kwi *= (1 - c1);
+            khi += c1;
+            const int c2 = (khi * p.kw == p.ntaps) ? 1 : 0;
+            khi *= (1 - c2);
+            kc += c2;
+        } else {
+            kc += 1;
+            const int c1 = (kc == p.st_per_tap) ? 1 : 0;
+            kc *= (1 - c1);
+            kwi += c1;
+            const int c2 = (kwi == p.kw) ? 1 : 0;
+            kwi *= (1 - c2);
+            khi += c2;
+        }
     };
+    int wtap = 0, wkc = 0;          // (tap, channel stage) of the NEXT weight request (DBG & 16 order)
     auto req_x = [&](int stage, int i) {
         if constexpr (DBG & 1) return;
         VK_GLDS16(xsrc[i], smem + (stage & (R_NSLOT - 1)) * R_SLOT + dma_x0 + i * 1024);
     };
     auto req_w = [&](int stage, int i) {
         if constexpr (DBG & 1) return;
-        VK_GLDS16(wsrc[i] + (long)stage * R_ROWB, smem + (stage & (R_NSLOT - 1)) * R_SLOT + dma_w0 + i * 1024);
+        long woff = (long)stage * R_ROWB;
+        if constexpr (DBG & 16) {
+            woff = (long)(wtap * p.st_per_tap + wkc) * R_ROWB;
+            if (i == 1) {
+                wtap += 1;
+                const int c = (wtap == p.ntaps) ? 1 : 0;
+                wtap *= (1 - c);
+                wkc += c;
+            }
+        }
+        VK_GLDS16((DBG & 32) ? p.zero : wsrc[i] + woff, smem + (stage & (R_NSLOT - 1)) * R_SLOT + dma_w0 + i * 1024);
     };
 
     // ---- fragment read addresses (bytes inside a slot) ----
@@ -401,6 +424,14 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<16>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<32>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<96>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
         attr_set = true;
     }
     Conv256K k;
@@ -426,6 +457,7 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     k.dil = a.dil;
     k.st_per_tap = a.Cin / 32;
     k.stages = a.kh * a.kw * k.st_per_tap;
+    k.ntaps = a.kh * a.kw;
     k.wrow_bytes = a.kh * a.kw * a.Cin * 2;
     k.relu = a.relu;
     k.m_tiles = ceil_div(k.M, R_BM);
@@ -445,6 +477,10 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
         case 3: hipLaunchKernelGGL(conv_mfma256_kernel<3>, grid, block, R_SMEM, stream, k); break;
         case 4: hipLaunchKernelGGL(conv_mfma256_kernel<4>, grid, block, R_SMEM, stream, k); break;
         case 8: hipLaunchKernelGGL(conv_mfma256_kernel<8>, grid, block, R_SMEM, stream, k); break;
+        case 16: hipLaunchKernelGGL(conv_mfma256_kernel<16>, grid, block, R_SMEM, stream, k); break;
+        case 32: hipLaunchKernelGGL(conv_mfma256_kernel<32>, grid, block, R_SMEM, stream, k); break;
+        case 64: hipLaunchKernelGGL(conv_mfma256_kernel<64>, grid, block, R_SMEM, stream, k); break;
+        case 96: hipLaunchKernelGGL(conv_mfma256_kernel<96>, grid, block, R_SMEM, stream, k); break;
         default: hipLaunchKernelGGL(conv_mfma256_kernel<0>, grid, block, R_SMEM, stream, k);
     }
     VK_CHECK_HIP(hipGetLastError());

@@ -71,6 +71,8 @@ struct ConvArgs {
 int launch_conv(const ConvArgs &a, hipStream_t stream);
 bool conv256_eligible(const ConvArgs &a);                 // conv_mfma256.hip
 int launch_conv256(const ConvArgs &a, hipStream_t stream);
+bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (LDS-resident input panel, 9 taps per fetch)
+int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv256b_eligible(const ConvArgs &a);                // conv_mfma256b.hip (128-byte LDS rows, 64-channel stages)
 int launch_conv256b(const ConvArgs &a, hipStream_t stream);
 
