@@ -56,13 +56,26 @@ CONV_CASES = [
     ("panel_d1", 3, 20, 31, 128, 256, 3, 1, 1, 1, False, True),
     ("panel_wide", 1, 18, 84, 192, 256, 3, 1, 1, 1, False, False),
     ("panel_wide_d1", 2, 30, 100, 128, 256, 3, 1, 1, 1, True, True),
+    ("panel_tiny", 1, 14, 14, 128, 256, 3, 1, 2, 2, False, True),      # M = 196 < one tile (last RoI chunk of a batch)
+    # two-workgroups-per-CU 1x1 kernel (128x256 tiles, 3-slot ring): stage counts 2, 4, 6, 10, 16 (prologue-only,
+    # tail-only and steady-state paths), an edge tile, stride 2, with and without residual / ReLU
+    ("duo_s2", 3, 24, 24, 64, 256, 1, 1, 0, 1, False, False),
+    ("duo_s4", 2, 24, 30, 128, 512, 1, 1, 0, 1, True, True),
+    ("duo_s6", 1, 33, 37, 192, 256, 1, 1, 0, 1, True, True),
+    ("duo_s10", 2, 23, 29, 320, 256, 1, 1, 0, 1, True, False),
+    ("duo_s16", 2, 30, 50, 512, 1024, 1, 1, 0, 1, True, True),
+    ("duo_s2_stride2", 2, 47, 51, 256, 512, 1, 2, 0, 1, False, True),
 ]
 
 
 @pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv(case, dt):
+def test_conv(case, dt, monkeypatch):
     _, N, H, W, cin, cout, k, stride, pad, dil, use_res, relu = case
+    # the dispatcher re-reads these per call: "ring_*" cases pin the 256x256 ring kernel, which the 1x1 /
+    # panel kernels would otherwise take over
+    monkeypatch.setenv("VK_CONV_DUO", "0" if case[0].startswith("ring_") else "1")
+    monkeypatch.setenv("VK_CONV3X3_PANEL", "0" if case[0].startswith("ring_") else "1")
     g = _rng(zlib.crc32(case[0].encode()))
     x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))
     w = (g.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)
@@ -81,6 +94,21 @@ def test_conv(case, dt):
     ref = q(ref)
     tol = 1e-3 if dt == L.VK_F16 else 2e-5
     assert G.rel_err(y, ref) <= tol
+
+
+def test_conv_1x1_kernels_bit_identical(monkeypatch):
+    """The two 1x1 kernels (256x256 ring, 128x256 two-per-CU) walk K in the same order with the same MFMA: a
+    layer's bits do not depend on which of them the dispatcher picks (it picks by problem size)."""
+    g = _rng(11)
+    x = torch.from_numpy(g.standard_normal((2, 256, 30, 40)).astype(np.float32))
+    w = (g.standard_normal((512, 256, 1, 1)) * 0.08).astype(np.float32)
+    b = g.standard_normal(512).astype(np.float32)
+    res = torch.from_numpy(g.standard_normal((2, 512, 30, 40)).astype(np.float32))
+    ys = []
+    for duo in ("0", "1"):
+        monkeypatch.setenv("VK_CONV_DUO", duo)
+        ys.append(G.conv2d(x, w, bias=b, residual_nchw=res, relu=True, dt=L.VK_F16))
+    assert torch.equal(ys[0], ys[1])
 
 
 def test_conv_bias_f32_out():

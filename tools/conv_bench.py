@@ -51,12 +51,14 @@ def main():
         if variants:      # interleaved A/B rounds in ONE process on ONE device (cdna guide rule 24)
             res_ms = {v: [] for v in variants}
             for rnd in range(int(os.environ.get("ROUNDS", "5"))):
-                for v in variants:
+                for vkey in variants:
+                    v = vkey
                     # a variant is "<dbg>" or "<kernel><dbg>", e.g. "0", "b0", "b1"
                     # "p..." = LDS-panel 3x3 kernel enabled, otherwise the im2col ring kernels
                     os.environ["VK_CONV3X3_PANEL"] = "1" if v[0] == "p" else "0"
+                    os.environ["VK_CONV_DUO"] = "1" if v[0] == "d" else "0"
                     os.environ["VK_CONV256_KERNEL"] = v[0] if v[0] in "ab" else "a"
-                    os.environ["VK_CONV256_DBG"] = v.lstrip("abp") or "0"
+                    os.environ["VK_CONV256_DBG"] = v.lstrip("abpd") or "0"
                     run()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,7 +67,7 @@ def main():
                         run()
                     e1.record()
                     torch.cuda.synchronize()
-                    res_ms[v].append(e0.elapsed_time(e1) / iters)
+                    res_ms[vkey].append(e0.elapsed_time(e1) / iters)
             fl = 2.0 * M * cout * cin * k * k
             print(name, " ".join(f"v{v}: med {np.median(t) * 1e3:.1f} us min {min(t) * 1e3:.1f} us "
                                  f"({fl / np.median(t) / 1e9:.0f} TF)" for v, t in res_ms.items()), flush=True)

@@ -392,7 +392,9 @@ bool conv3x3_panel_eligible(const ConvArgs &a) {
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cin % 64 != 0 || a.Cin < 128) return false;
     if (panel_pp(a) == 0) return false;
     if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets
-    return (long)a.N * a.H * a.W >= 4 * 256;
+    // no lower bound on M: the K walk (channel-stage major, tap minor) sums in a different order than the
+    // im2col kernels, and a layer's bits must not depend on how many RoIs share a launch (head chunking)
+    return true;
 }
 
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {

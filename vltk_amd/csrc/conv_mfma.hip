@@ -331,6 +331,7 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
+    if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
     if (conv256_eligible(a)) {
         const char *v = getenv("VK_CONV256_KERNEL");      // "a" | "b": A/B switch, re-read per call
         if (v && v[0] == 'b' && conv256b_eligible(a)) return launch_conv256b(a, stream);

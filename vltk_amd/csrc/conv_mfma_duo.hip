@@ -1,0 +1,413 @@
+// 1x1 convolution (any stride, no padding) as a 128x256-tile GEMM with TWO co-resident workgroups per CU.
+//
+// Why: the 256x256 ring kernel (conv_mfma256.hip) owns the CU, so a tile's epilogue (residual read +
+// output write: 256 KiB of HBM traffic, ~13 us at the CU's fair share of HBM when every CU does it at
+// once) cannot overlap anything: for the small-K 1x1 layers (Res5 conv3: K = 512) the memory phase is as
+// long as the MFMA phase and the two add up.  Here a workgroup is 4 waves (one per
+// SIMD, each 128 pixels x 64 channels: the same per-wave geometry, fragment layout and hand-issued
+// ds_read schedule as the ring kernel) with a 72 KiB LDS ring, so two workgroups share a CU and one's
+// epilogue runs under the other's MFMA loop.  (The two de-phase by themselves: in-kernel stamps show ~90 % of
+// epilogue time under the co-resident workgroup's MFMA loop; a forced start skew changed nothing and was removed.)
+//
+//   * tile 128 pixels x 256 channels; K stages of 32 channels (64-B LDS rows, XOR swizzle on the DMA source);
+//     ring of 3 slots x (8 KiB pixels + 16 KiB weights); per stage a wave issues 2 pixel + 4 weight pieces
+//     (global_load_lds_dwordx4, saddr form: 32-bit per-lane offsets from the uniform tensor base).
+//   * stage s: rows 0-2 carry the last three weight pieces of stage s+2; the barrier sits after row 4
+//     (vmcnt(6): stage s+1 landed, only the six pieces of stage s+2 may be outstanding); rows 5-7 carry the
+//     two pixel pieces and the first weight piece of stage s+3 into the slot the barrier just freed.
+//   * rows >= M are clamped to row M-1 for the loads and masked at the store (no zero page: a 1x1 conv has
+//     no padded taps).
+//   * epilogue through LDS in two 64-row halves ([64][256] f32 = 64 KiB), whole 512-B rows to HBM.
+#include <cstdio>
+#include <type_traits>
+#include <vector>
+
+#include "vk_common.h"
+
+namespace vk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct DuoK {
+    const char *x;
+    const char *w;
+    const float *bias;
+    const char *res;
+    char *y;
+    int H, W, Ho, Wo, HoWo, M;
+    int cin_bytes, ldy;
+    int stride;
+    int stages;               // Cin / 32
+    int wrow_bytes;           // Cin * 2
+    int relu;
+    int m_tiles, n_tiles;
+    unsigned long *stamps;    // STAMP builds only: 8 words per workgroup (phase times, HW_ID, XCC_ID)
+};
+
+constexpr int D_BM = 128, D_BN = 256, D_NSLOT = 3;
+constexpr int D_XB = D_BM * 64;              // 8 KiB
+constexpr int D_SLOT = D_XB + D_BN * 64;     // 24 KiB
+constexpr int D_SMEM = D_NSLOT * D_SLOT;     // 72 KiB
+
+#define VKD_GLDS16(gptr, lptr)                                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// STAMP: diagnostic build (VK_DUO_STAMPS=<file>): wave 0 records s_memrealtime at the phase boundaries into a
+// buffer nothing else reads (cdna guide section 7, in-kernel stamps); never used by the product path.
+template <bool STAMP>
+__global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long ts[5];
+    if constexpr (STAMP) ts[0] = __builtin_amdgcn_s_memrealtime();
+
+    // XCD-aware (bijective) workgroup -> tile map: consecutive tiles (same pixel rows, next channel block)
+    // stay on one XCD's L2
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int n_tile = t % p.n_tiles, m_tile = t / p.n_tiles;
+    const int m0 = m_tile * D_BM, n0 = n_tile * D_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = channel block of 64
+    const int g = lane >> 4, j = lane & 15;
+
+    // ---- LDS-DMA source state: pixel rows (wave*2+i)*16 + (lane>>2), weight rows (wave*4+i)*16 + (lane>>2) ----
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
+    unsigned a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = min(m0 + (wave * 2 + i) * 16 + lrow, p.M - 1);
+        const int n_img = m / p.HoWo;
+        const int rem = m - n_img * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_off[i] = (unsigned)((n_img * p.H + ho * p.stride) * p.W + wo * p.stride) * (unsigned)p.cin_bytes + lchunk * 16;
+    }
+    const unsigned wsrc0 = (unsigned)(n0 + wave * 64 + lrow) * (unsigned)p.wrow_bytes + lchunk * 16;
+    const unsigned wstep = 16u * p.wrow_bytes;
+    auto req_x = [&](int stage, int slot, int i) {
+        unsigned a = a_off[i];
+        asm volatile("" : "+v"(a));     // opaque: keeps the add in the loop instead of a register per (stage, piece)
+        VKD_GLDS16(p.x + (a + (unsigned)stage * 64u), smem + slot * D_SLOT + (wave * 2 + i) * 1024);
+    };
+    auto req_w = [&](int stage, int slot, int i) {
+        unsigned a = wsrc0;
+        asm volatile("" : "+v"(a));
+        VKD_GLDS16(p.w + (a + i * wstep + (unsigned)stage * 64u), smem + slot * D_SLOT + D_XB + (wave * 4 + i) * 1024);
+    };
+
+    // ---- fragment read addresses ----
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    const unsigned x_a = lds0 + j * 64 + ((g ^ ((-(j >> 2)) & 3)) << 4);                 // + mi*1024
+    unsigned w_a[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int wrow = wave * 64 + (j >> 2) * 8 + par * 4 + (j & 3);                   // + (ni>>1)*32 rows
+        w_a[par] = lds0 + D_XB + wrow * 64 + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
+    }
+
+    floatx4 acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 wa[4], wb[4], xw[4];
+    const int S = p.stages;
+
+    // hand-issued fragment reads with counted waits (see conv_mfma256.hip: hipcc would wait lgkmcnt(0) at
+    // every use while an LDS-DMA is in flight)
+#define VKD_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define VKD_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
+#define VKD_SB() __builtin_amdgcn_sched_barrier(0)
+#define VKD_MMA_ROW(MI, XR, WF)                                                                      \
+    do {                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                               \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0);                \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+    } while (0)
+#define VKD_READ_W(WF, so)                  \
+    VKD_DSR(WF[0], w_a[0] + so, 0);         \
+    VKD_DSR(WF[1], w_a[1] + so, 0);         \
+    VKD_DSR(WF[2], w_a[0] + so, 2048);      \
+    VKD_DSR(WF[3], w_a[1] + so, 2048)
+
+    // FULL: steady state (stage s+3 exists): constant waits, no branches.  !FULL: the last stages.
+    // slot = s % 3 (uniform, carried by the caller); slot of s+2 = slot of s-1, slot of s+3 = slot of s.
+    auto stage_body = [&](auto full_c, int s, int slot, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // slot of stage s+1
+        const int slot_p = slot == 0 ? D_NSLOT - 1 : slot - 1;       // slot of stage s+2 (= s-1)
+        const unsigned xs = x_a + (unsigned)slot * D_SLOT, xn = x_a + (unsigned)slot_n * D_SLOT;
+        const bool more = FULL || (s + 1 < S);
+        const bool rw = FULL || (s + 2 < S);
+        const bool rx = FULL || (s + 3 < S);
+        VKD_DSR(xw[3], xs, 3072); VKD_WAIT3(xw[0]); VKD_SB(); VKD_MMA_ROW(0, xw[0], wcur); VKD_SB();
+        if (rw) req_w(s + 2, slot_p, 1);
+        VKD_SB();
+        VKD_DSR(xw[0], xs, 4096); VKD_WAIT3(xw[1]); VKD_SB(); VKD_MMA_ROW(1, xw[1], wcur); VKD_SB();
+        if (rw) req_w(s + 2, slot_p, 2);
+        VKD_SB();
+        VKD_DSR(xw[1], xs, 5120); VKD_WAIT3(xw[2]); VKD_SB(); VKD_MMA_ROW(2, xw[2], wcur); VKD_SB();
+        if (rw) req_w(s + 2, slot_p, 3);
+        VKD_SB();
+        VKD_DSR(xw[2], xs, 6144); VKD_WAIT3(xw[3]); VKD_SB(); VKD_MMA_ROW(3, xw[3], wcur); VKD_SB();
+        VKD_DSR(xw[3], xs, 7168); VKD_WAIT3(xw[0]); VKD_SB(); VKD_MMA_ROW(4, xw[0], wcur); VKD_SB();
+        if (more) {
+            // all reads of stage s are issued.  vmcnt: stage s+1 landed <=> only the six pieces of stage s+2
+            // (all issued by now) may be outstanding; lgkmcnt(0) + barrier: slot(s) is free for stage s+3.
+            if (FULL || s + 2 < S)
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+            VKD_SB();
+            const unsigned sn = (unsigned)slot_n * D_SLOT;
+            VKD_READ_W(wnext, sn);
+            VKD_DSR(xw[0], xn, 0);
+            VKD_SB();
+            VKD_MMA_ROW(5, xw[1], wcur);
+            VKD_SB();
+            if (rx) req_x(s + 3, slot, 0);
+            VKD_DSR(xw[1], xn, 1024);
+            VKD_SB();
+            VKD_MMA_ROW(6, xw[2], wcur);
+            VKD_SB();
+            if (rx) req_x(s + 3, slot, 1);
+            VKD_DSR(xw[2], xn, 2048);
+            VKD_SB();
+            VKD_MMA_ROW(7, xw[3], wcur);
+            VKD_SB();
+            if (rx) req_w(s + 3, slot, 0);
+            VKD_SB();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
+            VKD_SB();
+            VKD_MMA_ROW(5, xw[1], wcur);
+            VKD_MMA_ROW(6, xw[2], wcur);
+            VKD_MMA_ROW(7, xw[3], wcur);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+
+    // ---- prologue: stages 0 and 1 completely, and the first three pieces of stage 2 ----
+    int issued = 0;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+        if (st < S) {
+            req_x(st, st, 0);
+            req_x(st, st, 1);
+            req_w(st, st, 0);
+            issued += 3;
+            if (st < 2) {
+                req_w(st, st, 1);
+                req_w(st, st, 2);
+                req_w(st, st, 3);
+                issued += 3;
+            }
+        }
+    }
+    // stage 0 (the 6 oldest pieces) must have landed
+    if (issued == 15)
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (issued == 12)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
+    VKD_READ_W(wa, 0u);
+    VKD_DSR(xw[0], x_a, 0);
+    VKD_DSR(xw[1], x_a, 1024);
+    VKD_DSR(xw[2], x_a, 2048);
+    int s = 0, slot = 0;
+    auto next_slot = [](int sl) { return sl == D_NSLOT - 1 ? 0 : sl + 1; };
+    for (; s + 4 < S; s += 2) {
+        stage_body(T_{}, s, slot, wa, wb);
+        slot = next_slot(slot);
+        stage_body(T_{}, s + 1, slot, wb, wa);
+        slot = next_slot(slot);
+    }
+    for (; s < S; s += 2) {
+        stage_body(F_{}, s, slot, wa, wb);
+        slot = next_slot(slot);
+        if (s + 1 < S) {
+            stage_body(F_{}, s + 1, slot, wb, wa);
+            slot = next_slot(slot);
+        }
+    }
+#undef VKD_DSR
+#undef VKD_WAIT3
+#undef VKD_MMA_ROW
+#undef VKD_READ_W
+#undef VKD_SB
+
+    // ---- epilogue: + bias (+ residual) (ReLU) -> f16 through LDS, two halves of 64 rows x 256 channels ----
+    asm volatile("s_barrier" ::: "memory");          // every wave has finished reading its fragments
+    if constexpr (STAMP) ts[2] = __builtin_amdgcn_s_memrealtime();
+    floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
+    auto load_res = [&](int h, half8 (&rr)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 256 * i, row = it >> 5, k8 = it & 31;
+            const int m = min(m0 + h * 64 + row, p.M - 1);
+            if (p.res)
+                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
+            else
+                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto stage_half = [&](auto h_c) {
+        constexpr int h = decltype(h_c)::value;
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+            const int col = wave * 64 + qn * 32 + g * 8;              // tile-local channel of this lane's 8 values
+            const floatx4 b0 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[0];
+            const floatx4 b1 = reinterpret_cast<const floatx4 *>(p.bias + n0 + col)[1];
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq) {
+                const int row = mq * 16 + j;
+                const int c16 = col >> 2;
+                stg[row * 64 + (c16 ^ (row & 7))] = acc[h * 4 + mq][2 * qn] + b0;
+                stg[row * 64 + ((c16 + 1) ^ (row & 7))] = acc[h * 4 + mq][2 * qn + 1] + b1;
+            }
+        }
+    };
+    auto write_half = [&](int h, const half8 (&rr)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int it = tid + 256 * i, row = it >> 5, k8 = it & 31;
+            const int m = m0 + h * 64 + row;
+            const floatx4 v0 = stg[row * 64 + ((2 * k8) ^ (row & 7))];
+            const floatx4 v1 = stg[row * 64 + ((2 * k8 + 1) ^ (row & 7))];
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = v0[e] + (float)rr[i][e], b = v1[e] + (float)rr[i][4 + e];
+                if (p.relu) {
+                    a = a > 0.f ? a : 0.f;
+                    b = b > 0.f ? b : 0.f;
+                }
+                o[e] = (_Float16)a;
+                o[4 + e] = (_Float16)b;
+            }
+            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
+        }
+    };
+#define VKD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    half8 r0[8], r1[8];
+    load_res(0, r0);
+    stage_half(std::integral_constant<int, 0>{});
+    VKD_LDS_BARRIER();
+    load_res(1, r1);
+    write_half(0, r0);
+    VKD_LDS_BARRIER();
+    if constexpr (STAMP) ts[3] = __builtin_amdgcn_s_memrealtime();
+    stage_half(std::integral_constant<int, 1>{});
+    VKD_LDS_BARRIER();
+    write_half(1, r1);
+#undef VKD_LDS_BARRIER
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[4] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long *o = p.stamps + (long)bid * 8;
+            for (int i = 0; i < 5; ++i) o[i] = ts[i];
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            o[7] = t;
+        }
+    }
+}
+
+bool conv_duo_eligible(const ConvArgs &a) {
+    const char *v = getenv("VK_CONV_DUO");               // "0" disables (A/B switch, re-read per call)
+    if (v && v[0] == '0') return false;
+    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
+    if (a.kh != 1 || a.kw != 1 || a.pad != 0) return false;
+    if (a.Cout % D_BN != 0 || a.ldy != a.Cout || a.Cin % 32 != 0 || a.Cin < 64) return false;
+    if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets
+    const long M = (long)a.N * a.Ho * a.Wo;
+    if (M < 8 * D_BM) return false;
+    // measured (interleaved A/B, one device): -10...-19 % on every K <= 512 layer and on the small-grid K = 1024
+    // layers; the large-grid K >= 1024 layers (Res5 conv1 / shortcut) are MFMA-loop bound and equal or 1-2 % slower
+    if (v && v[0] == '1') return true;                   // "1" forces it wherever it is legal (A/B, tests)
+    return a.Cin <= 512 || M < 400000;
+}
+
+int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, D_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, D_SMEM));
+        attr_set = true;
+    }
+    DuoK k;
+    k.x = (const char *)a.x;
+    k.w = (const char *)a.w;
+    k.bias = a.bias;
+    k.res = (const char *)a.res;
+    k.y = (char *)a.y;
+    k.H = a.H;
+    k.W = a.W;
+    k.Ho = a.Ho;
+    k.Wo = a.Wo;
+    k.HoWo = a.Ho * a.Wo;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    VK_REQUIRE(M > 0 && M < (1L << 31) - D_BM, VK_EINVAL, "conv_duo: M=%ld out of range", M);
+    VK_REQUIRE((long)a.N * a.H * a.W * a.Cin * 2 < (1L << 32) && (long)a.Cout * a.Cin * 2 < (1L << 32), VK_EINVAL,
+               "conv_duo: tensor beyond the 32-bit DMA offsets");
+    k.M = (int)M;
+    k.cin_bytes = a.Cin * 2;
+    k.ldy = a.ldy;
+    k.stride = a.stride;
+    k.stages = a.Cin / 32;
+    k.wrow_bytes = a.Cin * 2;
+    k.relu = a.relu;
+    k.m_tiles = ceil_div(k.M, D_BM);
+    k.n_tiles = a.Cout / D_BN;
+    KernelTimer *tm = g_timer;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (tm) {
+        e0 = tm->get();
+        e1 = tm->get();
+        VK_CHECK_HIP(hipEventRecord(e0, stream));
+    }
+    const dim3 grid(k.m_tiles * k.n_tiles), block(256);
+    k.stamps = nullptr;
+    if (const char *sf = getenv("VK_DUO_STAMPS")) {      // diagnostic: one launch, phase stamps appended to the file
+        const size_t nb = (size_t)grid.x * 8 * sizeof(unsigned long);
+        VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
+        hipLaunchKernelGGL(conv_duo_kernel<true>, grid, block, D_SMEM, stream, k);
+        VK_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long> h((size_t)grid.x * 8);
+        VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
+        VK_CHECK_HIP(hipFree(k.stamps));
+        if (FILE *f = fopen(sf, "a")) {
+            fprintf(f, "# launch M=%d cout=%d cin=%d grid=%u\n", k.M, a.Cout, a.Cin, grid.x);
+            for (unsigned b = 0; b < grid.x; ++b) {
+                fprintf(f, "%u", b);
+                for (int i = 0; i < 8; ++i) fprintf(f, " %lu", h[(size_t)b * 8 + i]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    } else
+        hipLaunchKernelGGL(conv_duo_kernel<false>, grid, block, D_SMEM, stream, k);
+    VK_CHECK_HIP(hipGetLastError());
+    if (tm) {
+        VK_CHECK_HIP(hipEventRecord(e1, stream));
+        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 1, a.stride,
+                            2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) +
+                                   (double)a.Cout * a.Cin)});
+    }
+    return VK_OK;
+}
+
+}  // namespace vk
