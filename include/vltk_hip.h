@@ -45,7 +45,7 @@ typedef enum { VK_F32 = 0, VK_F16 = 1, VK_I64 = 2, VK_I32 = 3 } vk_dtype;
  * 1230-1237, 1312-1336, 1414-1417, 1537, 1583-1607). */
 typedef struct vk_config {
     int32_t depth;                 /* RESNETS.DEPTH 50|101|152 */
-    int32_t num_groups;            /* RESNETS.NUM_GROUPS (only 1 supported this round) */
+    int32_t num_groups;            /* RESNETS.NUM_GROUPS (frcnn.py:217; > 1: ResNeXt, width_per_group a power of two) */
     int32_t width_per_group;       /* RESNETS.WIDTH_PER_GROUP */
     int32_t stem_out_channels;     /* RESNETS.STEM_OUT_CHANNELS */
     int32_t res2_out_channels;     /* RESNETS.RES2_OUT_CHANNELS */
@@ -167,19 +167,23 @@ int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *fl
 
 /* Packed-weight helpers (host side).  K is ordered (kh, kw, cin) and padded to
  * whole 128-byte K-tiles; rows are padded to a multiple of 128 output channels. */
-size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, vk_dtype dt);
+size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, int groups, vk_dtype dt);
 int vk_packed_cout(int cout);
-/* w_oihw [cout,cin,kh,kw] f32; bn = {gamma,beta,mean,var} each [cout] or NULL;
+/* Grouped convolutions (ResNeXt, BottleneckBlock conv2 `groups=num_groups` frcnn.py:942-952) run as dense GEMMs over an
+ * input-channel SLICE per 64-output-channel tile: slice = min(max(cin/groups, 64), cin) channels, weights
+ * zero outside a channel's own group.  Needs cin == cout and cin/groups a power of two.  groups == 1: dense. */
+int vk_conv_slice_channels(int cin, int groups);
+/* w_oihw [cout,cin/groups,kh,kw] f32; bn = {gamma,beta,mean,var} each [cout] or NULL;
  * bias [cout] or NULL; outputs: packed weights (dtype dt) and f32 bias [vk_packed_cout]. */
 int vk_pack_conv_weight(const float *w_oihw_host, const float *bn_host, const float *bias_host,
-                        int cout, int cin, int kh, int kw, vk_dtype dt,
+                        int cout, int cin, int kh, int kw, int groups, vk_dtype dt,
                         void *w_packed_host, float *bias_packed_host);
 
 /* conv + folded-BN bias (+ residual) (+ ReLU)  <- Conv2d.forward frcnn.py:794-822,
  * BottleneckBlock.forward :963-979.  x [N,H,W,cin] (dt), residual/y [N*Ho*Wo, ldy]. */
 int vk_conv2d(const void *x, int N, int H, int W, int cin,
               const void *w_packed, const float *bias_packed, const void *residual,
-              void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil,
+              void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil, int groups,
               int relu, vk_dtype dt, vk_dtype out_dt, void *stream);
 
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */

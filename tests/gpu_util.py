@@ -45,11 +45,12 @@ def to_nchw(y_nhwc, dt):
     return out.cpu()
 
 
-def pack_conv(w, bn, bias, dt):
-    """w [cout,cin,kh,kw] f32 numpy; bn = (gamma,beta,mean,var) or None -> device (packed weights, bias)."""
+def pack_conv(w, bn, bias, dt, groups=1):
+    """w [cout,cin/groups,kh,kw] f32 numpy; bn = (gamma,beta,mean,var) or None -> device (packed weights, bias)."""
     w = np.ascontiguousarray(w, dtype=np.float32)
     cout, cin, kh, kw = w.shape
-    nbytes = L.load().vk_packed_weight_bytes(cout, cin, kh, kw, dt)
+    cin *= groups
+    nbytes = L.load().vk_packed_weight_bytes(cout, cin, kh, kw, groups, dt)
     wp = np.zeros(nbytes, dtype=np.uint8)
     bp = np.zeros(L.load().vk_packed_cout(cout), dtype=np.float32)
     bnp = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32) for v in bn])) if bn is not None else None
@@ -57,15 +58,16 @@ def pack_conv(w, bn, bias, dt):
     L.call("vk_pack_conv_weight", w.ctypes.data_as(C.c_void_p),
            bnp.ctypes.data_as(C.c_void_p) if bnp is not None else None,
            bi.ctypes.data_as(C.c_void_p) if bi is not None else None,
-           cout, cin, kh, kw, dt, wp.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p))
+           cout, cin, kh, kw, groups, dt, wp.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p))
     return torch.from_numpy(wp).to(DEV), torch.from_numpy(bp).to(DEV)
 
 
 def conv2d(x_nchw, w, bn=None, bias=None, residual_nchw=None, stride=1, pad=0, dil=1, relu=False, dt=L.VK_F16,
-           out_dt=None):
+           out_dt=None, groups=1):
     out_dt = dt if out_dt is None else out_dt
     cout, cin, kh, kw = w.shape
-    wd, bd = pack_conv(w, bn, bias, dt)
+    cin *= groups
+    wd, bd = pack_conv(w, bn, bias, dt, groups)
     x = to_nhwc(x_nchw, dt)
     N, H, W, _ = x.shape
     Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -77,7 +79,7 @@ def conv2d(x_nchw, w, bn=None, bias=None, residual_nchw=None, stride=1, pad=0, d
         assert ldy == cout
         res = to_nhwc(residual_nchw, dt)
     L.call("vk_conv2d", P(x), N, H, W, cin, P(wd), P(bd), P(res), P(y), cout, ldy, kh, kw, stride, pad, dil,
-           int(relu), dt, out_dt, stream())
+           groups, int(relu), dt, out_dt, stream())
     return to_nchw(y, out_dt)[:, :cout]
 
 

@@ -151,6 +151,23 @@ def test_e2e_fp16_fast_vs_emulating_oracle(setup, golden):
             assert e <= 3e-2
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 1e-3)])
+def test_e2e_resnext_grouped_vs_oracle(precision, tol):
+    """ResNeXt bottlenecks (NUM_GROUPS > 1, frcnn.py:217-219, 942-952, 1367-1381) through the whole pipeline, every
+    stage against the oracle (whose grouped block is pinned by the reference's `blk_groups` golden vector)."""
+    cfg = vg_c4_config(depth=50, num_groups=8, width_per_group=8, post_nms_topk=24, detections=8)
+    sd = make_state_dict(cfg, seed=77)
+    x = synthetic_images(2, 160, 224, seed=5)
+    shapes = [[160, 224], [144, 200]]
+    x[1, :, 144:, :] = 0
+    x[1, :, :, 200:] = 0
+    m, out = run_gpu(cfg, sd, torch.from_numpy(x), shapes, precision)
+    oracle = FRCNNOracle(cfg, sd, emulate=None if precision == "fp32" else "fp16")
+    res4 = nchw(m.get_stage("res4"))
+    assert G.rel_err(res4, oracle.backbone(torch.from_numpy(x))) <= (1e-4 if precision == "fp32" else 5e-3)
+    stage_chain_check(m, out, oracle, shapes, tol=tol)
+
+
 def test_chunking_and_determinism(setup):
     """Results do not depend on the Res5 RoI chunk size and are bit-reproducible run to run."""
     cfg, sd, x, shapes = setup

@@ -96,6 +96,32 @@ def test_conv(case, dt, monkeypatch):
     assert G.rel_err(y, ref) <= tol
 
 
+GROUPED_CASES = [
+    # name, N,H,W, channels, groups, stride, dil   (BottleneckBlock conv2 of ResNeXt: frcnn.py:942-952)
+    ("x152_res2", 2, 20, 27, 256, 32, 1, 1),        # 8 channels per group
+    ("x152_res3", 1, 17, 19, 512, 32, 1, 1),        # 16
+    ("x152_res4", 1, 13, 15, 1024, 32, 1, 1),       # 32
+    ("x152_res5", 3, 14, 14, 2048, 32, 1, 2),       # 64, dilation 2 (RoI head)
+    ("wide_groups", 1, 11, 13, 256, 2, 1, 1),       # 128 per group: slice wider than the output tile
+    ("stride2", 1, 21, 22, 128, 4, 2, 1),           # STRIDE_IN_1X1 = false puts the stride on conv2
+]
+
+
+@pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("case", GROUPED_CASES, ids=[c[0] for c in GROUPED_CASES])
+def test_grouped_conv(case, dt):
+    _, N, H, W, c, groups, stride, dil = case
+    g = _rng(zlib.crc32(case[0].encode()))
+    x = torch.from_numpy(g.standard_normal((N, c, H, W)).astype(np.float32))
+    w = (g.standard_normal((c, c // groups, 3, 3)) * (2.0 / (c // groups * 9)) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, c), g.standard_normal(c) * 0.1, g.standard_normal(c) * 0.1, g.uniform(0.5, 1.5, c))
+    y = G.conv2d(x, w, bn=bn, stride=stride, pad=dil, dil=dil, relu=True, dt=dt, groups=groups)
+    wf, bf = G.fold_ref(w, bn, dt)
+    q = (lambda t: t.half().float()) if dt == L.VK_F16 else (lambda t: t)
+    ref = q(F.relu(F.conv2d(q(x), wf, None, stride, dil, dil, groups) + bf.view(1, -1, 1, 1)))
+    assert G.rel_err(y, ref) <= (1e-3 if dt == L.VK_F16 else 2e-5)
+
+
 def test_conv_1x1_kernels_bit_identical(monkeypatch):
     """The two 1x1 kernels (256x256 ring, 128x256 two-per-CU) walk K in the same order with the same MFMA: a
     layer's bits do not depend on which of them the dispatcher picks (it picks by problem size)."""
@@ -126,6 +152,36 @@ def test_conv_bias_f32_out():
 @pytest.fixture(scope="module")
 def kat(golden_dir):
     return np.load(os.path.join(golden_dir, "kat_ops.npz"))
+
+
+@pytest.mark.parametrize("tag", ["blk_s2_in1x1", "blk_s2_in3x3", "blk_identity", "blk_dil2", "blk_groups"])
+def test_bottleneck_kat(kat, tag):
+    """BottleneckBlock.forward (frcnn.py:963-979) chained from vk_conv2d calls, fp32 strict mode, against the
+    reference's own output: stride in the 1x1 / in the 3x3, identity shortcut, dilation 2, groups 8."""
+    cin, cout, mid, stride, groups, s1x1, dil = kat[tag + "/args"].tolist()
+    sd = {k.split("/sd/")[1]: kat[k] for k in kat.files if k.startswith(tag + "/sd/")}
+    x = torch.from_numpy(kat[tag + "/x"])
+    if mid * 4 % 128:       # fp32 K-tiles are 32 channels: widen a 16-channel bottleneck with zero channels (same math)
+        assert groups == 1
+        pad = 32 - mid
+        sd["conv1.weight"] = np.concatenate([sd["conv1.weight"], np.zeros((pad, cin, 1, 1), np.float32)])
+        w2 = np.zeros((32, 32, 3, 3), np.float32)
+        w2[:mid, :mid] = sd["conv2.weight"]
+        sd["conv2.weight"] = w2
+        sd["conv3.weight"] = np.concatenate([sd["conv3.weight"], np.zeros((cout, pad, 1, 1), np.float32)], axis=1)
+        for c in ("conv1", "conv2"):
+            for n, v in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+                sd[f"{c}.norm.{n}"] = np.concatenate([sd[f"{c}.norm.{n}"], np.full(pad, v, np.float32)])
+
+    def bn(p):
+        return tuple(sd[f"{p}.norm.{n}"] for n in ("weight", "bias", "running_mean", "running_var"))
+    s1, s3 = (stride, 1) if s1x1 else (1, stride)
+    dt = L.VK_F32
+    sc = G.conv2d(x, sd["shortcut.weight"], bn=bn("shortcut"), stride=stride, dt=dt) if "shortcut.weight" in sd else x
+    t = G.conv2d(x, sd["conv1.weight"], bn=bn("conv1"), stride=s1, relu=True, dt=dt)
+    t = G.conv2d(t, sd["conv2.weight"], bn=bn("conv2"), stride=s3, pad=dil, dil=dil, relu=True, dt=dt, groups=groups)
+    y = G.conv2d(t, sd["conv3.weight"], bn=bn("conv3"), residual_nchw=sc, relu=True, dt=dt)
+    assert G.rel_err(y, kat[tag + "/y"]) <= 2e-5
 
 
 @pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])

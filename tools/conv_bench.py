@@ -46,7 +46,7 @@ def main():
 
         def run():
             L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad,
-                   dil, 1, L.VK_F16, L.VK_F16, G.stream())
+                   dil, 1, 1, L.VK_F16, L.VK_F16, G.stream())
         M = N * Ho * Wo
         if variants:      # interleaved A/B rounds in ONE process on ONE device (cdna guide rule 24)
             res_ms = {v: [] for v in variants}

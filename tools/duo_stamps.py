@@ -34,7 +34,7 @@ def main():
     res = torch.randn((N, Ho, Wo, cout), device=G.DEV).half() if use_res else None
 
     def run():
-        L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad, dil, 1,
+        L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad, dil, 1, 1,
                L.VK_F16, L.VK_F16, G.stream())
     os.environ["VK_CONV_DUO"] = "1"
     for _ in range(20):

@@ -81,10 +81,11 @@ SIGNATURES = {
     "vk_get_stage_timing": (_I, [_P, C.POINTER(_F)]),
     "vk_enable_kernel_timing": (_I, [_P, _I]),
     "vk_get_kernel_timing": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_D), C.POINTER(_D), C.POINTER(_D), _I]),
-    "vk_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "vk_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "vk_conv_slice_channels": (_I, [_I, _I]),
     "vk_packed_cout": (_I, [_I]),
-    "vk_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "vk_conv2d": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vk_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "vk_conv2d": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "vk_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "vk_packed_stem_bytes": (_SZ, [_I, _I]),

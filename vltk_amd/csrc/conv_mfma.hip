@@ -42,6 +42,7 @@ struct ConvK {
     int ldy;
     int kw, stride, pad, dil;
     int ktiles, kt_per_tap;
+    int slice_bytes;     // grouped conv: bytes of the input-channel slice a 64-channel output tile reads (0: dense)
     int wrow_bytes;      // ktiles * 128
     int relu;
     int m_tiles, n_tiles;
@@ -181,7 +182,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
             }
         } else {
             const int dh = khi * p.dil, dw = kwi * p.dil;
-            const long toff = ((long)dh * p.W + dw) * p.cin_bytes + cb + chunk * 16;
+            // grouped: the tile's 64 output channels only see the slice of input channels their groups own
+            const int sl = p.slice_bytes ? (n0 * ES / p.slice_bytes) * p.slice_bytes : 0;
+            const long toff = ((long)dh * p.W + dw) * p.cin_bytes + sl + cb + chunk * 16;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 bool ok = (unsigned)(bh[i] + dh) < (unsigned)p.H && (unsigned)(bw[i] + dw) < (unsigned)p.W;
@@ -330,12 +333,15 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
-    if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
-    if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
-    if (conv256_eligible(a)) {
-        const char *v = getenv("VK_CONV256_KERNEL");      // "a" | "b": A/B switch, re-read per call
-        if (v && v[0] == 'b' && conv256b_eligible(a)) return launch_conv256b(a, stream);
-        return launch_conv256(a, stream);
+    const bool grouped = a.groups > 1;
+    if (!grouped) {
+        if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
+        if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
+        if (conv256_eligible(a)) {
+            const char *v = getenv("VK_CONV256_KERNEL");      // "a" | "b": A/B switch, re-read per call
+            if (v && v[0] == 'b' && conv256b_eligible(a)) return launch_conv256b(a, stream);
+            return launch_conv256(a, stream);
+        }
     }
     const int es = (int)dtype_size(a.dt);
     VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32, VK_EINVAL, "conv: dtype must be f16 or f32");
@@ -363,11 +369,22 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     k.pad = a.pad;
     k.dil = a.dil;
     k.relu = a.relu;
+    k.slice_bytes = 0;
     if (a.stem) {
         VK_REQUIRE(a.Cin == 4 && a.kh == 7 && a.kw == 7 && a.stride == 2, VK_EINVAL, "conv: stem mode is 7x7 s2 on NHWC4");
         k.pad = 0;
         k.kt_per_tap = 1;
         k.ktiles = (es == 2) ? 4 : 7;
+    } else if (grouped) {
+        // slice-diagonal GEMM (vk_pack_conv_weight): every 64-channel output tile multiplies the input-channel
+        // slice its groups own by weights that are zero outside each channel's group
+        VK_REQUIRE(a.Cin == a.Cout && a.Cin % a.groups == 0, VK_EINVAL, "conv: grouped needs Cin == Cout, Cin %% groups == 0");
+        const int sw = vk_conv_slice_channels(a.Cin, a.groups);
+        VK_REQUIRE(sw > 0 && (sw * es) % CONV_KTILE_BYTES == 0, VK_EINVAL,
+                   "conv: grouped slice of %d channels is not a whole number of K-tiles for this dtype", sw);
+        k.slice_bytes = sw * es;
+        k.kt_per_tap = k.slice_bytes / CONV_KTILE_BYTES;
+        k.ktiles = a.kh * a.kw * k.kt_per_tap;
     } else {
         VK_REQUIRE(k.cin_bytes % CONV_KTILE_BYTES == 0, VK_EINVAL,
                    "conv: Cin=%d must be a multiple of %d for this dtype", a.Cin, CONV_KTILE_BYTES / es);
@@ -375,11 +392,11 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         k.ktiles = a.kh * a.kw * k.kt_per_tap;
     }
     k.wrow_bytes = k.ktiles * CONV_KTILE_BYTES;
-    k.alg_flops = 2.0 * (double)k.M * a.Cout * (a.stem ? 147.0 : (double)a.kh * a.kw * a.Cin);
+    k.alg_flops = 2.0 * (double)k.M * a.Cout * (a.stem ? 147.0 : (double)a.kh * a.kw * a.Cin / (grouped ? a.groups : 1));
     k.alg_bytes = (double)a.N * a.H * a.W * a.Cin * es + (double)k.M * a.Cout * (dtype_size(a.out_dt) + (a.res ? es : 0)) +
-                  (double)a.Cout * a.kh * a.kw * a.Cin * es;
+                  (double)a.Cout * a.kh * a.kw * a.Cin / (grouped ? a.groups : 1) * es;
     k.m_tiles = ceil_div(k.M, CONV_BM);
-    const bool narrow = a.Cout <= 64 || a.stem;
+    const bool narrow = a.Cout <= 64 || a.stem || grouped;
     k.n_tiles = ceil_div(a.Cout, narrow ? 64 : 128);
     const bool f32out = (a.out_dt == VK_F32);
     if (a.dt == VK_F16) {

@@ -72,6 +72,7 @@ struct ConvLayer {
     bool bn = true, relu = false;
     void *w = nullptr;       // device, packed
     float *b = nullptr;      // device, [packed_cout]
+    int groups = 1;          // conv2 of a ResNeXt bottleneck (frcnn.py:950)
 };
 
 struct Block {
@@ -139,7 +140,7 @@ static void add_conv_names(std::vector<std::string> &n, const std::string &p, bo
 }
 
 static Block make_block(const std::string &p, int cin, int cmid, int cout, int stride, int dil, bool stride_in_1x1,
-                        std::vector<std::string> &names) {
+                        int groups, std::vector<std::string> &names) {
     Block b;
     const int s1 = stride_in_1x1 ? stride : 1, s3 = stride_in_1x1 ? 1 : stride;   // frcnn.py:932
     b.has_shortcut = cin != cout;
@@ -149,6 +150,7 @@ static Block make_block(const std::string &p, int cin, int cmid, int cout, int s
     }
     b.conv1 = ConvLayer{p + ".conv1", cin, cmid, 1, s1, 0, 1, true, true};
     b.conv2 = ConvLayer{p + ".conv2", cmid, cmid, 3, s3, dil, dil, true, true};
+    b.conv2.groups = groups;                                                        // frcnn.py:950
     b.conv3 = ConvLayer{p + ".conv3", cmid, cout, 1, 1, 0, 1, true, true};   // relu after the residual add
     add_conv_names(names, b.conv1.prefix, true);
     add_conv_names(names, b.conv2.prefix, true);
@@ -187,7 +189,7 @@ static const HostTensor *get_t(vk_handle *h, const std::string &name, std::vecto
 }
 
 static int finalize_conv(vk_handle *h, ConvLayer &L) {
-    const HostTensor *w = get_t(h, L.prefix + ".weight", {L.cout, L.cin, L.k, L.k});
+    const HostTensor *w = get_t(h, L.prefix + ".weight", {L.cout, L.cin / L.groups, L.k, L.k});
     if (!w) return VK_EWEIGHTS;
     std::vector<float> bn;
     const float *bnp = nullptr, *bias = nullptr;
@@ -205,10 +207,10 @@ static int finalize_conv(vk_handle *h, ConvLayer &L) {
         if (!t) return VK_EWEIGHTS;
         bias = t->data.data();
     }
-    const size_t wb = vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, h->dt);
+    const size_t wb = vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, L.groups, h->dt);
     std::vector<char> packed(wb);
     std::vector<float> pb(vk_packed_cout(L.cout));
-    VK_TRY(vk_pack_conv_weight(w->data.data(), bnp, bias, L.cout, L.cin, L.k, L.k, h->dt, packed.data(), pb.data()));
+    VK_TRY(vk_pack_conv_weight(w->data.data(), bnp, bias, L.cout, L.cin, L.k, L.k, L.groups, h->dt, packed.data(), pb.data()));
     VK_TRY(upload(h, packed.data(), wb, &L.w));
     VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&L.b));
     return VK_OK;
@@ -367,6 +369,7 @@ static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int 
     a.stride = L.stride;
     a.pad = L.pad;
     a.dil = L.dil;
+    a.groups = L.groups;
     a.relu = relu;
     a.stem = 0;
     a.dt = h->dt;
@@ -409,21 +412,36 @@ int vk_version(void) { return 1; }
 
 int vk_packed_cout(int cout) { return (cout + CONV_COUT_ALIGN - 1) / CONV_COUT_ALIGN * CONV_COUT_ALIGN; }
 
-size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, vk_dtype dt) {
-    return (size_t)vk_packed_cout(cout) * kh * kw * cin * dtype_size(dt);
+int vk_conv_slice_channels(int cin, int groups) {
+    if (groups <= 1) return cin;
+    if (cin <= 0 || cin % groups != 0) return -1;
+    const int cpg = cin / groups;
+    if (cpg & (cpg - 1)) return -1;                     // power of two: slices and groups nest
+    return std::min(std::max(cpg, 64), cin);
 }
 
-int vk_pack_conv_weight(const float *w, const float *bn, const float *bias, int cout, int cin, int kh, int kw, vk_dtype dt,
-                        void *w_packed, float *bias_packed) {
+size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, int groups, vk_dtype dt) {
+    const int sw = vk_conv_slice_channels(cin, groups);
+    return sw <= 0 ? 0 : (size_t)vk_packed_cout(cout) * kh * kw * sw * dtype_size(dt);
+}
+
+int vk_pack_conv_weight(const float *w, const float *bn, const float *bias, int cout, int cin, int kh, int kw, int groups,
+                        vk_dtype dt, void *w_packed, float *bias_packed) {
     VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "pack: dtype must be f16 or f32");
-    VK_REQUIRE((cin * (int)dtype_size(dt)) % CONV_KTILE_BYTES == 0, VK_EINVAL,
-               "pack: cin=%d is not a whole number of 128-byte K-tiles for this dtype", cin);
+    VK_REQUIRE(groups >= 1, VK_EINVAL, "pack: groups=%d", groups);
+    const int sw = vk_conv_slice_channels(cin, groups);     // K channels per tap in the packed row (== cin when dense)
+    VK_REQUIRE(sw > 0, VK_EINVAL, "pack: cin=%d / groups=%d must be a power of two", cin, groups);
+    VK_REQUIRE(groups == 1 || cin == cout, VK_EINVAL, "pack: grouped convolution needs cin == cout (got %d, %d)", cin, cout);
+    VK_REQUIRE((sw * (int)dtype_size(dt)) % CONV_KTILE_BYTES == 0, VK_EINVAL,
+               "pack: %d channels per tap is not a whole number of 128-byte K-tiles for this dtype", sw);
     const int cp = vk_packed_cout(cout);
-    const size_t K = (size_t)kh * kw * cin;
+    const int cpg = cin / groups;                           // input channels of one group (= row length of w_oihw)
+    const size_t K = (size_t)kh * kw * sw;
     std::vector<float> row(K);
     for (int co = 0; co < cp; ++co) {
         double s = 1.0;
         float b = 0.f;
+        std::fill(row.begin(), row.end(), 0.f);
         if (co < cout) {
             if (bn) {   // eval BatchNorm folded into the conv: eps 1e-5 (nn.BatchNorm2d default)
                 const double g = bn[co], be = bn[cout + co], mu = bn[2 * (size_t)cout + co], var = bn[3 * (size_t)cout + co];
@@ -432,12 +450,14 @@ int vk_pack_conv_weight(const float *w, const float *bn, const float *bias, int 
             } else if (bias) {
                 b = bias[co];
             }
-            for (int c = 0; c < cin; ++c)
+            // the slice this channel's 64-wide output tile reads starts at slice0; its own group at g0
+            const int slice0 = groups == 1 ? 0 : (co / 64 * 64) / sw * sw;
+            const int g0 = groups == 1 ? 0 : co / cpg * cpg;
+            for (int c = 0; c < cpg; ++c)
                 for (int y = 0; y < kh; ++y)
                     for (int x = 0; x < kw; ++x)
-                        row[((size_t)y * kw + x) * cin + c] = (float)((double)w[(((size_t)co * cin + c) * kh + y) * kw + x] * s);
-        } else {
-            std::fill(row.begin(), row.end(), 0.f);
+                        row[((size_t)y * kw + x) * sw + (g0 + c - slice0)] =
+                            (float)((double)w[(((size_t)co * cpg + c) * kh + y) * kw + x] * s);
         }
         bias_packed[co] = b;
         to_dt(row.data(), K, dt, (char *)w_packed + (size_t)co * K * dtype_size(dt));
@@ -478,9 +498,9 @@ int vk_pack_stem_weight(const float *w, const float *bn, int cout, vk_dtype dt, 
 }
 
 int vk_conv2d(const void *x, int N, int H, int W, int cin, const void *w_packed, const float *bias_packed,
-              const void *residual, void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil, int relu,
-              vk_dtype dt, vk_dtype out_dt, void *stream) {
-    VK_REQUIRE(kh == kw && kh >= 1 && stride >= 1 && dil >= 1 && pad >= 0, VK_EINVAL, "conv2d: bad geometry");
+              const void *residual, void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil, int groups,
+              int relu, vk_dtype dt, vk_dtype out_dt, void *stream) {
+    VK_REQUIRE(kh == kw && kh >= 1 && stride >= 1 && dil >= 1 && pad >= 0 && groups >= 1, VK_EINVAL, "conv2d: bad geometry");
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
@@ -501,6 +521,7 @@ int vk_conv2d(const void *x, int N, int H, int W, int cin, const void *w_packed,
     a.stride = stride;
     a.pad = pad;
     a.dil = dil;
+    a.groups = groups;
     a.relu = relu;
     a.dt = dt;
     a.out_dt = out_dt;
@@ -566,7 +587,9 @@ int vk_stem(const float *x, int N, int H, int W, const void *w_packed, const flo
 int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     VK_REQUIRE(cfg && out, VK_EINVAL, "create: null argument");
     VK_REQUIRE(cfg->depth == 50 || cfg->depth == 101 || cfg->depth == 152, VK_EINVAL, "create: depth %d unsupported", cfg->depth);
-    VK_REQUIRE(cfg->num_groups == 1, VK_EINVAL, "create: grouped 3x3 convolutions (NUM_GROUPS=%d) are not built yet", cfg->num_groups);
+    VK_REQUIRE(cfg->num_groups >= 1 && cfg->width_per_group >= 1 &&
+                   (cfg->num_groups == 1 || (cfg->width_per_group & (cfg->width_per_group - 1)) == 0),
+               VK_EINVAL, "create: NUM_GROUPS=%d needs WIDTH_PER_GROUP (%d) to be a power of two", cfg->num_groups, cfg->width_per_group);
     VK_REQUIRE(cfg->res5_halve == 0, VK_EINVAL, "create: RES5HALVE=true is not supported");
     VK_REQUIRE(cfg->stride_in_1x1 != 0, VK_EINVAL,
                "create: STRIDE_IN_1X1=false leaves a stride-2 conv2 in res5 (frcnn.py:1351-1355) -- not supported");
@@ -594,7 +617,7 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
         for (int b = 0; b < kBlocks[di][s]; ++b) {
             const int stride = (b == 0 && s > 0) ? 2 : 1;   // frcnn.py:237
             h->stages[s].push_back(make_block(std::string("backbone.") + sn[s] + "." + std::to_string(b), cin, cmid, cout,
-                                              stride, 1, cfg->stride_in_1x1 != 0, h->names));
+                                              stride, 1, cfg->stride_in_1x1 != 0, cfg->num_groups, h->names));
             cin = cout;
         }
         cout *= 2;
@@ -613,7 +636,7 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     const int mid5 = cfg->num_groups * cfg->width_per_group * 8;
     cin = h->res4_c;
     for (int b = 0; b < 3; ++b) {   // VG res5: stride 1, conv2 dilation/padding 2 (frcnn.py:1345-1355)
-        h->res5.push_back(make_block("roi_heads.res5." + std::to_string(b), cin, mid5, h->res5_c, 1, 2, true, h->names));
+        h->res5.push_back(make_block("roi_heads.res5." + std::to_string(b), cin, mid5, h->res5_c, 1, 2, true, cfg->num_groups, h->names));
         cin = h->res5_c;
     }
     const int C = cfg->num_classes, F = h->res5_c;
@@ -706,9 +729,9 @@ int vk_finalize(vk_handle *h) {
         std::vector<float> w(wo->data), b(bo->data);
         w.insert(w.end(), wd->data.begin(), wd->data.end());
         b.insert(b.end(), bd->data.begin(), bd->data.end());
-        std::vector<char> packed(vk_packed_weight_bytes(5 * A, hid, 1, 1, h->dt));
+        std::vector<char> packed(vk_packed_weight_bytes(5 * A, hid, 1, 1, 1, h->dt));
         std::vector<float> pb(vk_packed_cout(5 * A));
-        VK_TRY(vk_pack_conv_weight(w.data(), nullptr, b.data(), 5 * A, hid, 1, 1, h->dt, packed.data(), pb.data()));
+        VK_TRY(vk_pack_conv_weight(w.data(), nullptr, b.data(), 5 * A, hid, 1, 1, 1, h->dt, packed.data(), pb.data()));
         VK_TRY(upload(h, packed.data(), packed.size(), &h->rpn_heads.w));
         VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&h->rpn_heads.b));
         const HostTensor *ca = get_t(h, "proposal_generator.anchor_generator.cell_anchors.0", {A, 4});

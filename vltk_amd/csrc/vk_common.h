@@ -64,6 +64,7 @@ struct ConvArgs {
     int N, H, W, Cin;    // input geometry (stem mode: padded Hp, Wp, 4)
     int Ho, Wo, Cout, ldy;
     int kh, kw, stride, pad, dil;
+    int groups;          // 0 / 1: dense; > 1: slice-diagonal weights (vk_pack_conv_weight), Cin == Cout
     int relu;
     int stem;            // 1: K-tiles are runs of consecutive input pixels (7x7 s2 stem)
     vk_dtype dt, out_dt;
