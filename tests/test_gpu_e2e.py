@@ -168,6 +168,26 @@ def test_e2e_resnext_grouped_vs_oracle(precision, tol):
     stage_chain_check(m, out, oracle, shapes, tol=tol)
 
 
+@pytest.mark.parametrize("tag", ["resnext50_8x8d", "r50_halve", "r50_halve_s3x3"])
+def test_e2e_config_variants_vs_reference_golden(golden_dir, tag):
+    """Strict mode against the reference's own output for ResNeXt groups, RES5HALVE=true and stride in the 3x3."""
+    from test_oracle_golden import variant_inputs
+    g = np.load(os.path.join(golden_dir, "e2e_variants.npz"))
+    cfg, sd, x, shapes = variant_inputs(g, tag)
+    m, out = run_gpu(cfg, sd, x, shapes, "fp32")
+    res4 = nchw(m.get_stage("res4"))
+    assert G.rel_err(res4[:, :32], g[f"{tag}/res4_c0_31"]) <= 1e-3
+    np.testing.assert_array_equal(out["preds_per_image"].numpy(), g[f"{tag}/preds_per_image"])
+    for i in range(len(shapes)):
+        np.testing.assert_array_equal(out["obj_ids"][i].cpu().numpy(), g[f"{tag}/obj_ids_{i}"])
+        np.testing.assert_array_equal(out["attr_ids"][i].cpu().numpy(), g[f"{tag}/attr_ids_{i}"])
+        for k in ("roi_features", "boxes", "obj_probs", "attr_probs"):
+            assert G.rel_err(out[k][i].cpu(), g[f"{tag}/{k}_{i}"]) <= 1e-3, (k, i)
+    # fast mode, stage by stage against the fp16-emulating oracle
+    m16, out16 = run_gpu(cfg, sd, x, shapes, "fp16")
+    stage_chain_check(m16, out16, FRCNNOracle(cfg, sd, emulate="fp16"), shapes, tol=1e-3)
+
+
 def test_chunking_and_determinism(setup):
     """Results do not depend on the Res5 RoI chunk size and are bit-reproducible run to run."""
     cfg, sd, x, shapes = setup

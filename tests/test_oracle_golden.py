@@ -161,3 +161,42 @@ def test_e2e_r101_small(golden_dir):
         close(out["attr_probs"][i], g[f"attr_probs_{i}"])
         close(out["boxes"][i], g[f"boxes_{i}"])
         close(out["roi_features"][i], g[f"roi_features_{i}"])
+
+
+VARIANTS = {   # tools/gen_golden.py VARIANTS: configuration switches of the reference the main fixture does not take
+    "resnext50_8x8d": [("resnets", "num_groups", 8), ("resnets", "width_per_group", 8)],
+    "r50_halve": [("roi_box_head", "res5halve", True)],
+    "r50_halve_s3x3": [("roi_box_head", "res5halve", True), ("resnets", "stride_in_1x1", False)],
+}
+
+
+def variant_inputs(g, tag):
+    n, h, w = g["nhw"].tolist()
+    cfg = vg_c4_config(depth=50, post_nms_topk=16, detections=6, overrides=VARIANTS[tag])
+    sd = make_state_dict(cfg, seed=int(g["seed"]))
+    x = torch.from_numpy(synthetic_images(n, h, w, seed=int(g["seed"])))
+    shapes = g["shapes"].tolist()
+    for i, (hh, ww) in enumerate(shapes):
+        x[i, :, hh:, :] = 0
+        x[i, :, :, ww:] = 0
+    return cfg, sd, x, shapes
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_e2e_config_variants(golden_dir, tag):
+    """ResNeXt groups / RES5HALVE / stride in the 3x3 (frcnn.py:217-219, 932, 942-952, 1345-1355): the oracle
+    against the reference's own end-to-end output for each switch."""
+    g = np.load(os.path.join(golden_dir, "e2e_variants.npz"))
+    cfg, sd, x, shapes = variant_inputs(g, tag)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out, st = FRCNNOracle(cfg, sd).forward(x, shapes, return_stages=True)
+    close(st["res4"][:, :32], g[f"{tag}/res4_c0_31"])
+    close(st["res4"].double().sum(dim=(2, 3)).float(), g[f"{tag}/res4_sum"])
+    close(st["feature_pooled"], g[f"{tag}/feature_pooled"])
+    np.testing.assert_array_equal(out["preds_per_image"].numpy(), g[f"{tag}/preds_per_image"])
+    for i in range(len(shapes)):
+        np.testing.assert_array_equal(out["obj_ids"][i].numpy(), g[f"{tag}/obj_ids_{i}"])
+        np.testing.assert_array_equal(out["attr_ids"][i].numpy(), g[f"{tag}/attr_ids_{i}"])
+        close(out["obj_probs"][i], g[f"{tag}/obj_probs_{i}"])
+        close(out["boxes"][i], g[f"{tag}/boxes_{i}"])
+        close(out["roi_features"][i], g[f"{tag}/roi_features_{i}"])

@@ -286,6 +286,69 @@ def e2e(ref, name, n, h, w, shapes, post_topk, det, seed, depth=101):
           "min cls margin %.2e" % out["cls_margin"].min())
 
 
+VARIANTS = {
+    # tag: config overrides (section, key, value) on the depth-50 build config
+    "resnext50_8x8d": [("resnets", "num_groups", 8), ("resnets", "width_per_group", 8)],
+    "r50_halve": [("roi_box_head", "res5halve", True)],
+    "r50_halve_s3x3": [("roi_box_head", "res5halve", True), ("resnets", "stride_in_1x1", False)],
+    # (CLS_AGNOSTIC_BBOX_REG=true is not a variant: the reference's do_nms indexes r*C + class into the R
+    #  class-agnostic boxes and raises IndexError, frcnn.py:127-129)
+}
+
+
+def variant_config_dict(tag, post_topk=16, det=6):
+    d = vg_c4_config_dict(depth=50, post_nms_topk=post_topk, detections=det)
+    for sec, key, val in VARIANTS[tag]:
+        d[sec][key] = val
+    return d
+
+
+def e2e_variants(ref, n=2, h=128, w=160, shapes=((128, 160), (112, 150)), seed=4321):
+    """Compact end-to-end vectors of the reference for configuration switches the main fixture does not take:
+    ResNeXt groups (frcnn.py:217-219, 942-952), RES5HALVE (:1345-1355), stride in the 3x3 (:932).  Weights are regenerated from the seed, never stored."""
+    out = {"nhw": np.asarray([n, h, w]), "shapes": np.asarray(shapes), "seed": np.asarray(seed)}
+    for tag in VARIANTS:
+        cfg = Config(variant_config_dict(tag))
+        sd = make_state_dict(cfg, seed=seed)
+        net = ref.FRCNN(cfg).eval()
+        net.load_state_dict(to_torch_sd(sd), strict=True)
+        images = torch.from_numpy(synthetic_images(n, h, w, seed=seed))
+        for i, (hh, ww) in enumerate(shapes):
+            images[i, :, hh:, :] = 0
+            images[i, :, :, ww:] = 0
+        st = {}
+        hooks = [
+            net.backbone.register_forward_hook(lambda m, i, o: st.__setitem__("res4", o["res4"])),
+            net.proposal_generator.rpn_head.register_forward_hook(lambda m, i, o: st.update(obj=o[0][0])),
+            net.roi_heads.register_forward_hook(lambda m, i, o: st.update(obj_logits=o[0], pooled=o[3])),
+        ]
+        with torch.no_grad():
+            o = net(images, torch.tensor(shapes))
+        for hk in hooks:
+            hk.remove()
+        tie_free(np_(st["obj"]), f"{tag} rpn logits")
+        out[f"{tag}/res4_c0_31"] = np_(st["res4"][:, :32])
+        out[f"{tag}/res4_sum"] = np_(st["res4"].double().sum(dim=(2, 3)).float())
+        out[f"{tag}/feature_pooled"] = np_(st["pooled"])
+        out[f"{tag}/preds_per_image"] = np_(o["preds_per_image"])
+        for k in ("obj_ids", "obj_probs", "attr_ids", "attr_probs", "boxes", "roi_features"):
+            for i in range(n):
+                out[f"{tag}/{k}_{i}"] = np_(o[k][i])
+        top2 = st["obj_logits"].softmax(-1)[:, :-1].topk(2, dim=-1).values
+        out[f"{tag}/cls_margin"] = np_(top2[:, 0] - top2[:, 1])
+        print(tag, "preds", out[f"{tag}/preds_per_image"], "res4 max %.2f" % float(st["res4"].max()),
+              "feat max %.2f" % float(st["pooled"].max()), "min cls margin %.2e" % out[f"{tag}/cls_margin"].min(),
+              "obj ids", out[f"{tag}/obj_ids_0"][:6])
+    np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
+    print("e2e_variants.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__" and "--variants" in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    e2e_variants(load_reference())
+    sys.exit(0)
+
 if __name__ == "__main__" and "--preprocess" not in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)

@@ -127,5 +127,9 @@ def vg_c4_config_dict(depth=101, num_groups=1, width_per_group=64,
     }
 
 
-def vg_c4_config(**kw):
-    return Config(vg_c4_config_dict(**kw))
+def vg_c4_config(overrides=(), **kw):
+    """`overrides`: (section, key, value) triples applied to the dict, e.g. ("roi_box_head", "res5halve", True)."""
+    d = vg_c4_config_dict(**kw)
+    for sec, key, val in overrides:
+        d[sec][key] = val
+    return Config(d)

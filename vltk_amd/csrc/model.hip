@@ -590,9 +590,11 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     VK_REQUIRE(cfg->num_groups >= 1 && cfg->width_per_group >= 1 &&
                    (cfg->num_groups == 1 || (cfg->width_per_group & (cfg->width_per_group - 1)) == 0),
                VK_EINVAL, "create: NUM_GROUPS=%d needs WIDTH_PER_GROUP (%d) to be a power of two", cfg->num_groups, cfg->width_per_group);
-    VK_REQUIRE(cfg->res5_halve == 0, VK_EINVAL, "create: RES5HALVE=true is not supported");
-    VK_REQUIRE(cfg->stride_in_1x1 != 0, VK_EINVAL,
-               "create: STRIDE_IN_1X1=false leaves a stride-2 conv2 in res5 (frcnn.py:1351-1355) -- not supported");
+    // RES5HALVE=false only resets conv1/shortcut strides (frcnn.py:1351-1352): with the stride on conv2 the
+    // reference's block 0 adds a 7x7 main path to a 14x14 shortcut and raises
+    VK_REQUIRE(cfg->stride_in_1x1 != 0 || cfg->res5_halve != 0, VK_EINVAL,
+               "create: STRIDE_IN_1X1=false with RES5HALVE=false leaves a stride-2 conv2 in res5 (frcnn.py:1351-1355): "
+               "the reference's residual add fails on the shapes");
     VK_REQUIRE(cfg->precision == VK_F16 || cfg->precision == VK_F32, VK_EINVAL, "create: precision must be VK_F16 or VK_F32");
     VK_REQUIRE(cfg->num_sizes >= 1 && cfg->num_sizes <= VK_MAX_ANCHOR_DIM && cfg->num_ratios >= 1 &&
                    cfg->num_ratios <= VK_MAX_ANCHOR_DIM, VK_EINVAL, "create: bad anchor configuration");
@@ -635,8 +637,12 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     h->res5_c = cfg->res2_out_channels * 8;
     const int mid5 = cfg->num_groups * cfg->width_per_group * 8;
     cin = h->res4_c;
-    for (int b = 0; b < 3; ++b) {   // VG res5: stride 1, conv2 dilation/padding 2 (frcnn.py:1345-1355)
-        h->res5.push_back(make_block("roi_heads.res5." + std::to_string(b), cin, mid5, h->res5_c, 1, 2, true, cfg->num_groups, h->names));
+    for (int b = 0; b < 3; ++b) {
+        // VG res5 (RES5HALVE=false): stride 1, conv2 dilation/padding 2 (frcnn.py:1345-1355);
+        // RES5HALVE=true: the plain stage, first stride 2 (frcnn.py:1373-1383)
+        const bool halve = cfg->res5_halve != 0;
+        h->res5.push_back(make_block("roi_heads.res5." + std::to_string(b), cin, mid5, h->res5_c, (halve && b == 0) ? 2 : 1,
+                                     halve ? 1 : 2, cfg->stride_in_1x1 != 0, cfg->num_groups, h->names));
         cin = h->res5_c;
     }
     const int C = cfg->num_classes, F = h->res5_c;
@@ -904,19 +910,22 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
     if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[3], s));
 
     // ---- RoI heads (Res5ROIHeads.forward frcnn.py:1391-1403), chunked over RoIs ----
-    const int P = p.P, S = P * P;
+    const int P = p.P;
     for (int k0 = 0; k0 < p.K; k0 += p.chunk) {
         const int kc = std::min(p.chunk, p.K - k0);
         VK_TRY(vk_roi_pool(res4, N, p.Hf, p.Wf, h->res4_c, p.rois + 5 * (size_t)k0, kc, 1.0f / 16.0f, P, p.pooled, h->dt, s));
         void *a = p.h_a, *b2 = p.h_b;
         const void *x = p.pooled;
+        int hh = P, ww = P;
         for (auto &blk : h->res5) {
             int ho, wo;
-            VK_TRY(run_block(h, blk, x, kc, P, P, p.h_t1, p.h_t2, p.h_sc, a, s, &ho, &wo));
+            VK_TRY(run_block(h, blk, x, kc, hh, ww, p.h_t1, p.h_t2, p.h_sc, a, s, &ho, &wo));
+            hh = ho;
+            ww = wo;
             x = a;
             std::swap(a, b2);
         }
-        VK_TRY(vk_mean_pool(x, kc, S, h->res5_c, p.feat + (size_t)k0 * h->res5_c, h->dt, s));
+        VK_TRY(vk_mean_pool(x, kc, hh * ww, h->res5_c, p.feat + (size_t)k0 * h->res5_c, h->dt, s));
     }
     if (p.chunk >= p.K) set_stage(h, "pooled", p.pooled, h->dt, {p.K, P, P, h->res4_c});
     set_stage(h, "feature_pooled", p.feat, VK_F32, {p.K, h->res5_c});
