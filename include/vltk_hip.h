@@ -186,6 +186,14 @@ int vk_conv2d(const void *x, int N, int H, int W, int cin,
               void *y, int cout, int ldy, int kh, int kw, int stride, int pad, int dil, int groups,
               int relu, vk_dtype dt, vk_dtype out_dt, void *stream);
 
+/* conv3 + projection shortcut of a stride-1 BottleneckBlock as ONE f16 GEMM (`out = conv3(t) ; out += shortcut(x)`,
+ * frcnn.py:970-977): y[M,cout] = relu?([x1 | x2] . W^T + bias (+ residual)), W rows = [conv3 row (cin1) | shortcut row
+ * (cin2)] as packed by vk_pack_conv_weight and concatenated per output channel, bias = the two folded biases
+ * summed.  cout % 256 == 0, cin1 and cin2 multiples of 64 (whole 128-byte K-tiles of the packer). */
+int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M,
+                    const void *w_packed, const float *bias_packed, const void *residual,
+                    void *y, int cout, int relu, void *stream);
+
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
 int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);
 int vk_nhwc_to_nchw(const void *x, int N, int C, int H, int W, float *y, vk_dtype dt, void *stream);

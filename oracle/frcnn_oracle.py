@@ -137,7 +137,7 @@ class FRCNNOracle:
         self._folded = {}
 
     # ---- conv + BN (+relu) : Conv2d.forward frcnn.py:794-822 -------------
-    def _conv_bn(self, x, prefix, stride=1, padding=0, dilation=1, groups=1, relu=False, residual=None):
+    def _conv_bn(self, x, prefix, stride=1, padding=0, dilation=1, groups=1, relu=False, residual=None, round_out=True):
         sd = self.sd
         if self.emulate is None:
             y = F.conv2d(x, sd[prefix + ".weight"], None, stride, padding, dilation, groups)
@@ -156,7 +156,7 @@ class FRCNNOracle:
             y = y + residual
         if relu:
             y = F.relu(y)
-        return _h(y)
+        return _h(y) if round_out else y
 
     def _conv_bias(self, x, prefix, padding=0, relu=False, round_out=True):
         w, b = self.sd[prefix + ".weight"], self.sd[prefix + ".bias"]
@@ -184,7 +184,13 @@ class FRCNNOracle:
         out = self._conv_bn(out, prefix + ".conv2", stride=s3, padding=dilation, dilation=dilation,
                             groups=self.groups, relu=True)
         if (prefix + ".shortcut.weight") in self.sd:
-            sc = self._conv_bn(x, prefix + ".shortcut", stride=stride if stride_shortcut is None else stride_shortcut)
+            ss = stride if stride_shortcut is None else stride_shortcut
+            w3, wsc = self.sd[prefix + ".conv3.weight"], self.sd[prefix + ".shortcut.weight"]
+            # fp16 emulation of the HIP path: a stride-1 projection shortcut is part of conv3's GEMM there
+            # (csrc/model.hip can_fuse_shortcut), so it is never rounded to f16 on its own
+            fused = (self.emulate is not None and ss == 1 and w3.shape[0] % 256 == 0 and w3.shape[1] % 32 == 0
+                     and wsc.shape[1] % 32 == 0)
+            sc = self._conv_bn(x, prefix + ".shortcut", stride=ss, round_out=not fused)
         else:
             sc = x
         return self._conv_bn(out, prefix + ".conv3", relu=True, residual=sc)

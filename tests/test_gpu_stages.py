@@ -122,6 +122,35 @@ def test_grouped_conv(case, dt):
     assert G.rel_err(y, ref) <= (1e-3 if dt == L.VK_F16 else 2e-5)
 
 
+@pytest.mark.parametrize("M,c1,c2,cout,res", [(1500, 64, 64, 256, False), (4000, 512, 1024, 512, False),
+                                              (130, 128, 256, 256, True), (2600, 128, 192, 256, True)])
+def test_conv1x1_dual(M, c1, c2, cout, res):
+    """conv3 + stride-1 projection shortcut as one GEMM (`out += shortcut`, frcnn.py:970-977): two inputs, K = c1 + c2."""
+    g = _rng(M + c1)
+    x1 = torch.from_numpy(g.standard_normal((M, c1)).astype(np.float32)).half()
+    x2 = torch.from_numpy(g.standard_normal((M, c2)).astype(np.float32)).half()
+    w1 = (g.standard_normal((cout, c1, 1, 1)) * (1.0 / c1) ** 0.5).astype(np.float32)
+    w2 = (g.standard_normal((cout, c2, 1, 1)) * (1.0 / c2) ** 0.5).astype(np.float32)
+    bn1 = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    bn2 = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    r = torch.from_numpy(g.standard_normal((M, cout)).astype(np.float32)).half() if res else None
+    p1, b1 = G.pack_conv(w1, bn1, None, L.VK_F16)
+    p2, b2 = G.pack_conv(w2, bn2, None, L.VK_F16)
+    rows = b1.numel()
+    wcat = torch.cat([p1.view(rows, c1 * 2), p2.view(rows, c2 * 2)], dim=1).contiguous()
+    x1d, x2d, rd = x1.to(G.DEV), x2.to(G.DEV), (r.to(G.DEV) if res else None)
+    y = torch.empty((M, cout), dtype=torch.float16, device=G.DEV)
+    L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y), cout, 1, G.stream())
+    torch.cuda.synchronize()
+    f1, fb1 = G.fold_ref(w1, bn1, L.VK_F16)
+    f2, fb2 = G.fold_ref(w2, bn2, L.VK_F16)
+    ref = x1.float() @ f1.view(cout, c1).t() + x2.float() @ f2.view(cout, c2).t() + (fb1 + fb2)
+    if res:
+        ref = ref + r.float()
+    ref = F.relu(ref).half().float()
+    assert G.rel_err(y.float().cpu(), ref) <= 1e-3
+
+
 def test_conv_1x1_kernels_bit_identical(monkeypatch):
     """The two 1x1 kernels (256x256 ring, 128x256 two-per-CU) walk K in the same order with the same MFMA: a
     layer's bits do not depend on which of them the dispatcher picks (it picks by problem size)."""

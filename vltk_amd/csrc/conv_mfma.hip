@@ -334,6 +334,11 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     const bool grouped = a.groups > 1;
+    if (a.x2) {
+        VK_REQUIRE(conv_duo_dual_ok(a), VK_EINVAL,
+                   "conv: the dual-source form is 1x1, stride 1, f16, Cout %% 256 == 0, Cin and Cin2 multiples of 32");
+        return launch_conv_duo(a, stream);
+    }
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
         if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);

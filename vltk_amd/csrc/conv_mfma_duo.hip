@@ -7,7 +7,8 @@
 // SIMD, each 128 pixels x 64 channels: the same per-wave geometry, fragment layout and hand-issued
 // ds_read schedule as the ring kernel) with a 72 KiB LDS ring, so two workgroups share a CU and one's
 // epilogue runs under the other's MFMA loop.  (The two de-phase by themselves: in-kernel stamps show ~90 % of
-// epilogue time under the co-resident workgroup's MFMA loop; a forced start skew changed nothing and was removed.)
+// epilogue time under the co-resident workgroup's MFMA loop; a forced start skew changed nothing and was removed,
+// and so were non-temporal residual loads / output stores: 0...-1 % on every shape.)
 //
 //   * tile 128 pixels x 256 channels; K stages of 32 channels (64-B LDS rows, XOR swizzle on the DMA source);
 //     ring of 3 slots x (8 KiB pixels + 16 KiB weights); per stage a wave issues 2 pixel + 4 weight pieces
@@ -18,6 +19,7 @@
 //   * rows >= M are clamped to row M-1 for the loads and masked at the store (no zero page: a 1x1 conv has
 //     no padded taps).
 //   * epilogue through LDS in two 64-row halves ([64][256] f32 = 64 KiB), whole 512-B rows to HBM.
+#include <algorithm>
 #include <cstdio>
 #include <type_traits>
 #include <vector>
@@ -38,7 +40,10 @@ struct DuoK {
     int H, W, Ho, Wo, HoWo, M;
     int cin_bytes, ldy;
     int stride;
-    int stages;               // Cin / 32
+    const char *x2;           // second K segment (stages >= split): pixel rows of [M, cin2], stride 1; or nullptr
+    int cin2_bytes;
+    int split;                // stages of the first segment (== stages when x2 is null)
+    int stages;               // (Cin + Cin2) / 32
     int wrow_bytes;           // Cin * 2
     int relu;
     int m_tiles, n_tiles;
@@ -86,12 +91,22 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         a_off[i] = (unsigned)((n_img * p.H + ho * p.stride) * p.W + wo * p.stride) * (unsigned)p.cin_bytes + lchunk * 16;
     }
+    // dual-source form (conv3 + projection shortcut as ONE GEMM, K = [conv3 input | block input]): the second
+    // segment's rows are the same pixels of another tensor
+    unsigned a2_off[2] = {0u, 0u};
+    if (p.x2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            a2_off[i] = (unsigned)min(m0 + (wave * 2 + i) * 16 + lrow, p.M - 1) * (unsigned)p.cin2_bytes + lchunk * 16;
+    }
     const unsigned wsrc0 = (unsigned)(n0 + wave * 64 + lrow) * (unsigned)p.wrow_bytes + lchunk * 16;
     const unsigned wstep = 16u * p.wrow_bytes;
     auto req_x = [&](int stage, int slot, int i) {
-        unsigned a = a_off[i];
+        const bool second = stage >= p.split;                        // uniform
+        unsigned a = second ? a2_off[i] : a_off[i];
         asm volatile("" : "+v"(a));     // opaque: keeps the add in the loop instead of a register per (stage, piece)
-        VKD_GLDS16(p.x + (a + (unsigned)stage * 64u), smem + slot * D_SLOT + (wave * 2 + i) * 1024);
+        const char *base = second ? p.x2 : p.x;
+        VKD_GLDS16(base + (a + (unsigned)(stage - (second ? p.split : 0)) * 64u), smem + slot * D_SLOT + (wave * 2 + i) * 1024);
     };
     auto req_w = [&](int stage, int slot, int i) {
         unsigned a = wsrc0;
@@ -324,7 +339,14 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     }
 }
 
+bool conv_duo_dual_ok(const ConvArgs &a) {
+    return a.x2 && !a.stem && a.dt == VK_F16 && a.out_dt == VK_F16 && a.kh == 1 && a.kw == 1 && a.pad == 0 && a.stride == 1 &&
+           a.groups <= 1 && a.Cout % D_BN == 0 && a.ldy == a.Cout && a.Cin % 32 == 0 && a.Cin2 % 32 == 0 && a.Cin >= 32 &&
+           a.Cin2 >= 32 && (long)a.N * a.H * a.W * std::max(a.Cin, a.Cin2) * 2 < (1L << 32);
+}
+
 bool conv_duo_eligible(const ConvArgs &a) {
+    if (a.x2) return conv_duo_dual_ok(a);
     const char *v = getenv("VK_CONV_DUO");               // "0" disables (A/B switch, re-read per call)
     if (v && v[0] == '0') return false;
     if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
@@ -361,14 +383,17 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     k.HoWo = a.Ho * a.Wo;
     const long M = (long)a.N * a.Ho * a.Wo;
     VK_REQUIRE(M > 0 && M < (1L << 31) - D_BM, VK_EINVAL, "conv_duo: M=%ld out of range", M);
-    VK_REQUIRE((long)a.N * a.H * a.W * a.Cin * 2 < (1L << 32) && (long)a.Cout * a.Cin * 2 < (1L << 32), VK_EINVAL,
+    VK_REQUIRE((long)a.N * a.H * a.W * a.Cin * 2 < (1L << 32) && (long)a.Cout * (a.Cin + a.Cin2) * 2 < (1L << 32), VK_EINVAL,
                "conv_duo: tensor beyond the 32-bit DMA offsets");
     k.M = (int)M;
     k.cin_bytes = a.Cin * 2;
     k.ldy = a.ldy;
     k.stride = a.stride;
-    k.stages = a.Cin / 32;
-    k.wrow_bytes = a.Cin * 2;
+    k.x2 = (const char *)a.x2;
+    k.cin2_bytes = a.x2 ? a.Cin2 * 2 : 0;
+    k.split = a.Cin / 32;
+    k.stages = (a.Cin + (a.x2 ? a.Cin2 : 0)) / 32;
+    k.wrow_bytes = (a.Cin + (a.x2 ? a.Cin2 : 0)) * 2;
     k.relu = a.relu;
     k.m_tiles = ceil_div(k.M, D_BM);
     k.n_tiles = a.Cout / D_BN;
@@ -403,9 +428,9 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 1, a.stride,
-                            2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) +
-                                   (double)a.Cout * a.Cin)});
+        const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
+        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, K, 1, a.stride,
+                            2.0 * ((double)a.N * a.H * a.W * K + (double)k.M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * K)});
     }
     return VK_OK;
 }

@@ -78,6 +78,10 @@ struct ConvLayer {
 struct Block {
     ConvLayer conv1, conv2, conv3, shortcut;
     bool has_shortcut = false;
+    // fp16 fast mode: conv3 and a stride-1 projection shortcut run as ONE GEMM over K = [conv3 input | block
+    // input] (`out += shortcut`, frcnn.py:970-977, without storing the shortcut): conv3.w / conv3.b then hold
+    // the concatenated rows and the summed bias, and shortcut.w stays null
+    bool fused_shortcut = false;
 };
 
 static const int kBlocks[3][4] = {{3, 4, 6, 3}, {3, 4, 23, 3}, {3, 8, 36, 3}};   // frcnn.py:226
@@ -216,11 +220,50 @@ static int finalize_conv(vk_handle *h, ConvLayer &L) {
     return VK_OK;
 }
 
+// BN-folded packed rows + bias of one conv on the host (finalize_conv without the upload)
+static int pack_conv_host(vk_handle *h, const ConvLayer &L, std::vector<char> &packed, std::vector<float> &pb) {
+    const HostTensor *w = get_t(h, L.prefix + ".weight", {L.cout, L.cin / L.groups, L.k, L.k});
+    if (!w) return VK_EWEIGHTS;
+    std::vector<float> bn(4 * (size_t)L.cout);
+    const char *parts[4] = {".norm.weight", ".norm.bias", ".norm.running_mean", ".norm.running_var"};
+    for (int i = 0; i < 4; ++i) {
+        const HostTensor *t = get_t(h, L.prefix + parts[i], {L.cout});
+        if (!t) return VK_EWEIGHTS;
+        memcpy(bn.data() + (size_t)i * L.cout, t->data.data(), sizeof(float) * L.cout);
+    }
+    packed.resize(vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, L.groups, h->dt));
+    pb.resize(vk_packed_cout(L.cout));
+    return vk_pack_conv_weight(w->data.data(), bn.data(), nullptr, L.cout, L.cin, L.k, L.k, L.groups, h->dt, packed.data(), pb.data());
+}
+
+// The same rule is restated in oracle/frcnn_oracle.py (fp16 emulation): keep the two in step.
+static bool can_fuse_shortcut(const vk_handle *h, const Block &b) {
+    static const bool off = getenv("VK_NO_FUSED_SHORTCUT") != nullptr;      // A/B switch
+    return !off && h->dt == VK_F16 && b.has_shortcut && b.shortcut.stride == 1 && b.conv3.cout % 256 == 0 &&
+           b.conv3.cin % 32 == 0 && b.shortcut.cin % 32 == 0;
+}
+
 static int finalize_block(vk_handle *h, Block &b) {
-    if (b.has_shortcut) VK_TRY(finalize_conv(h, b.shortcut));
     VK_TRY(finalize_conv(h, b.conv1));
     VK_TRY(finalize_conv(h, b.conv2));
-    VK_TRY(finalize_conv(h, b.conv3));
+    b.fused_shortcut = can_fuse_shortcut(h, b);
+    if (!b.fused_shortcut) {
+        if (b.has_shortcut) VK_TRY(finalize_conv(h, b.shortcut));
+        return finalize_conv(h, b.conv3);
+    }
+    std::vector<char> w3, wsc;
+    std::vector<float> b3, bsc;
+    VK_TRY(pack_conv_host(h, b.conv3, w3, b3));
+    VK_TRY(pack_conv_host(h, b.shortcut, wsc, bsc));
+    const size_t r3 = (size_t)b.conv3.cin * 2, rsc = (size_t)b.shortcut.cin * 2, rows = b3.size();
+    std::vector<char> cat(rows * (r3 + rsc));
+    for (size_t r = 0; r < rows; ++r) {
+        memcpy(cat.data() + r * (r3 + rsc), w3.data() + r * r3, r3);
+        memcpy(cat.data() + r * (r3 + rsc) + r3, wsc.data() + r * rsc, rsc);
+        b3[r] += bsc[r];
+    }
+    VK_TRY(upload(h, cat.data(), cat.size(), &b.conv3.w));
+    VK_TRY(upload(h, b3.data(), b3.size() * sizeof(float), (void **)&b.conv3.b));
     return VK_OK;
 }
 
@@ -350,10 +393,13 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
 }
 
 static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int H, int W, const void *res, void *y,
-                    bool relu, vk_dtype out_dt, int ldy, hipStream_t s, int *Ho = nullptr, int *Wo = nullptr) {
+                    bool relu, vk_dtype out_dt, int ldy, hipStream_t s, int *Ho = nullptr, int *Wo = nullptr,
+                    const void *x2 = nullptr, int cin2 = 0) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
+    a.x2 = x2;
+    a.Cin2 = cin2;
     a.w = L.w;
     a.bias = L.b;
     a.res = res;
@@ -384,12 +430,14 @@ static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, 
                      void *y, hipStream_t s, int *Ho, int *Wo) {
     int h1, w1, h2, w2;
     const void *res = x;
-    if (b.has_shortcut) {
+    if (b.has_shortcut && !b.fused_shortcut) {
         VK_TRY(run_conv(h, b.shortcut, x, N, H, W, nullptr, sc, false, h->dt, 0, s));
         res = sc;
     }
     VK_TRY(run_conv(h, b.conv1, x, N, H, W, nullptr, t1, true, h->dt, 0, s, &h1, &w1));
     VK_TRY(run_conv(h, b.conv2, t1, N, h1, w1, nullptr, t2, true, h->dt, 0, s, &h2, &w2));
+    if (b.fused_shortcut)      // stride-1 block: t2 and x cover the same pixels
+        return run_conv(h, b.conv3, t2, N, h2, w2, nullptr, y, true, h->dt, 0, s, Ho, Wo, x, b.shortcut.cin);
     VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo));
     return VK_OK;
 }
@@ -525,6 +573,33 @@ int vk_conv2d(const void *x, int N, int H, int W, int cin, const void *w_packed,
     a.relu = relu;
     a.dt = dt;
     a.out_dt = out_dt;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M, const void *w_packed, const float *bias_packed,
+                    const void *residual, void *y, int cout, int relu, void *stream) {
+    VK_REQUIRE(x1 && x2 && M > 0 && M < (1L << 31), VK_EINVAL, "conv1x1_dual: bad arguments");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x1;
+    a.x2 = x2;
+    a.Cin = cin1;
+    a.Cin2 = cin2;
+    a.w = w_packed;
+    a.bias = bias_packed;
+    a.res = residual;
+    a.y = y;
+    a.N = 1;
+    a.H = a.Ho = 1;
+    a.W = a.Wo = (int)M;
+    a.Cout = cout;
+    a.ldy = cout;
+    a.kh = a.kw = 1;
+    a.stride = 1;
+    a.dil = 1;
+    a.groups = 1;
+    a.relu = relu;
+    a.dt = a.out_dt = VK_F16;
     return launch_conv(a, (hipStream_t)stream);
 }
 

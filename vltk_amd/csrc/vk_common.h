@@ -65,6 +65,8 @@ struct ConvArgs {
     int Ho, Wo, Cout, ldy;
     int kh, kw, stride, pad, dil;
     int groups;          // 0 / 1: dense; > 1: slice-diagonal weights (vk_pack_conv_weight), Cin == Cout
+    const void *x2;      // dual-source 1x1 (conv3 + projection shortcut in one GEMM): second input [M, Cin2], K = Cin | Cin2
+    int Cin2;
     int relu;
     int stem;            // 1: K-tiles are runs of consecutive input pixels (7x7 s2 stem)
     vk_dtype dt, out_dt;
@@ -76,6 +78,7 @@ bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (1x1 convs: 128x256 tile, two workgroups per CU)
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
+bool conv_duo_dual_ok(const ConvArgs &a);                 // the dual-source form has no other kernel
 bool conv256b_eligible(const ConvArgs &a);                // conv_mfma256b.hip (128-byte LDS rows, 64-channel stages)
 int launch_conv256b(const ConvArgs &a, hipStream_t stream);
 
