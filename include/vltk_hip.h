@@ -194,6 +194,16 @@ int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M,
                     const void *w_packed, const float *bias_packed, const void *residual,
                     void *y, int cout, int relu, void *stream);
 
+/* Last Res5 conv3 with the RoI's spatial mean folded into its epilogue (`res5(x).mean(dim=[2,3])`, frcnn.py:1401):
+ * out_mean[n][c] = mean over the HW rows of image n of relu?(x . W^T + bias + residual), summed EXACTLY (integer
+ * accumulation of the f16-rounded values) and rounded once, so it does not depend on how rows fall into tiles;
+ * a non-finite value gives NaN.  The [N*HW, cout] tensor itself is never written.  f16, 128 <= HW <= 255,
+ * cout % 256 == 0. */
+size_t vk_conv1x1_meanpool_workspace_bytes(int N, int HW, int cout);
+int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_packed, const float *bias_packed,
+                        const void *residual, int cout, int relu, float *out_mean,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
 int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);
 int vk_nhwc_to_nchw(const void *x, int N, int C, int H, int W, float *y, vk_dtype dt, void *stream);

@@ -151,6 +151,75 @@ def test_conv1x1_dual(M, c1, c2, cout, res):
     assert G.rel_err(y.float().cpu(), ref) <= 1e-3
 
 
+@pytest.mark.parametrize("N,HW,cin,cout", [(7, 196, 128, 256), (23, 196, 512, 512), (3, 255, 64, 256), (1, 128, 64, 256)])
+def test_conv1x1_meanpool(N, HW, cin, cout):
+    """Last Res5 conv3 + residual + ReLU with `.mean(dim=[2,3])` (frcnn.py:1401) folded into the epilogue: equal to
+    conv -> f16 -> mean, and bit-reproducible."""
+    g = _rng(N * HW)
+    M = N * HW
+    x = torch.from_numpy(g.standard_normal((M, cin)).astype(np.float32)).half()
+    r = torch.from_numpy(g.standard_normal((M, cout)).astype(np.float32)).half()
+    w = (g.standard_normal((cout, cin, 1, 1)) * (1.0 / cin) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    wp, bp = G.pack_conv(w, bn, None, L.VK_F16)
+    xd, rd = x.to(G.DEV), r.to(G.DEV)
+    nb = L.load().vk_conv1x1_meanpool_workspace_bytes(N, HW, cout)
+    outs = []
+    for _ in range(2):
+        ws = torch.empty(nb, dtype=torch.uint8, device=G.DEV)
+        out = torch.empty((N, cout), dtype=torch.float32, device=G.DEV)
+        L.call("vk_conv1x1_meanpool", G.P(xd), N, HW, cin, G.P(wp), G.P(bp), G.P(rd), cout, 1, G.P(out), G.P(ws), nb, G.stream())
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    wf, bf = G.fold_ref(w, bn, L.VK_F16)
+    y = F.relu(x.float() @ wf.view(cout, cin).t() + bf + r.float()).half().float()
+    ref = y.view(N, HW, cout).mean(dim=1)
+    assert G.rel_err(outs[0], ref) <= 1e-3
+    # position independence: the same images behind a different number of leading rows give the same bits
+    if N > 2:
+        k = 2
+        out2 = torch.empty((N - k, cout), dtype=torch.float32, device=G.DEV)
+        ws = torch.empty(nb, dtype=torch.uint8, device=G.DEV)
+        xs, rs = xd[k * HW:].contiguous(), rd[k * HW:].contiguous()
+        L.call("vk_conv1x1_meanpool", G.P(xs), N - k, HW, cin, G.P(wp), G.P(bp), G.P(rs), cout, 1, G.P(out2), G.P(ws), nb, G.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out2.cpu(), outs[0][k:])
+
+
+@pytest.mark.parametrize("kernel", ["duo", "ring", "panel"])
+def test_conv_reproducible_at_scale(kernel, monkeypatch):
+    """Thousands of workgroups, launched back to back: bit-identical output run to run and no wrong block.  (A copy
+    of a fragment register whose hand-issued ds_read was still in flight once made rare 16-row blocks wrong on a
+    loaded GPU: tests/test_asm_hazards.py checks the compiled code, this checks the device.)"""
+    monkeypatch.setenv("VK_CONV_DUO", "1" if kernel == "duo" else "0")
+    monkeypatch.setenv("VK_CONV3X3_PANEL", "1" if kernel == "panel" else "0")
+    g = _rng(99)
+    k = 3 if kernel == "panel" else 1
+    pad = dil = 2 if k == 3 else 1
+    if k == 1:
+        pad = 0
+    N, H, W, cin, cout = (64, 14, 14, 256, 512) if kernel == "panel" else (300, 14, 14, 512, 2048)
+    M = N * H * W
+    x = torch.randn((N, H, W, cin)).half().to(G.DEV)
+    r = torch.randn((M, cout)).half().to(G.DEV)
+    w = (g.standard_normal((cout, cin, k, k)) * (1.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+    wp, bp = G.pack_conv(w, None, np.zeros(cout, np.float32), L.VK_F16)
+    ys = []
+    for _ in range(4):
+        y = torch.empty((M, cout), dtype=torch.float16, device=G.DEV)
+        L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wp), G.P(bp), G.P(r), G.P(y), cout, cout, k, k, 1, pad, dil, 1, 1,
+               L.VK_F16, L.VK_F16, G.stream())
+        torch.cuda.synchronize()
+        ys.append(y)
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y)
+    wf = torch.from_numpy(w).half().float().to(G.DEV)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wf, None, 1, pad, dil).permute(0, 2, 3, 1).reshape(M, cout)
+    ref = F.relu(ref + r.float())
+    assert float((ys[0].float() - ref).abs().max()) <= 0.02 * float(ref.abs().max())
+
+
 def test_conv_1x1_kernels_bit_identical(monkeypatch):
     """The two 1x1 kernels (256x256 ring, 128x256 two-per-CU) walk K in the same order with the same MFMA: a
     layer's bits do not depend on which of them the dispatcher picks (it picks by problem size)."""

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Scan the gfx950 ISA of the hand-scheduled kernels for uses of in-flight ds_read destinations.
+
+The MFMA kernels issue their LDS fragment reads from inline asm and wait for them with counted
+`s_waitcnt lgkmcnt(N)`.  hipcc does not know those reads are asynchronous: wherever it decides to move a fragment
+register (loop back-edges and exits, operand set-up of a tied asm operand behind a branch) it emits a plain
+`v_mov` of a register whose read may not have landed yet -- stale data, timing dependent, found on MI355X as
+rare wrong 16-row blocks.  The kernels are therefore written so that every loop boundary and branch follows an
+`s_waitcnt lgkmcnt(0)`; this script proves it on the compiled code: it compiles each source to assembly, replays
+the LDS read queue (reads return in order; `lgkmcnt(N)` retires all but the N newest) and reports every
+instruction that touches a register with a pending read.
+
+usage: python tools/check_asm_hazards.py [file.hip ...]      exit code 1 if any hazard is found
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+CSRC = os.path.join(ROOT, "vltk_amd", "csrc")
+DEFAULT = ["conv_mfma256.hip", "conv_mfma_duo.hip", "conv3x3_panel.hip"]
+
+
+def _regs(tok):
+    out = []
+    for m in re.finditer(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]", tok):
+        if m.group(1):
+            out.append(int(m.group(1)))
+        else:
+            out += list(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def scan_function(lines):
+    """lines: the instructions of one kernel.  Returns [(line_no, text, pending_read_line)]."""
+    pend, found = [], []
+    for i, raw in enumerate(lines):
+        t = raw.split(";")[0].strip()
+        if not t or t.endswith(":") or t.startswith("."):
+            continue
+        parts = t.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        ops = [a.strip() for a in args.split(",")]
+        if op.startswith("ds_read"):
+            pend.append((i, set(_regs(ops[0]))))
+            continue
+        m = re.match(r"s_waitcnt.*lgkmcnt\((\d+)\)", t)
+        if m:
+            n = int(m.group(1))
+            if n == 0:
+                pend = []
+            elif n < len(pend):
+                pend = pend[len(pend) - n:]
+            continue
+        if op.startswith("s_"):
+            continue
+        used = set()
+        for a in ops:
+            used |= set(_regs(a))
+        for li, rs in pend:
+            if used & rs:
+                found.append((i, t, li))
+    return found
+
+
+def scan_file(path, hipcc="hipcc"):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                        "-S", "--cuda-device-only", path, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        src = open(out).read().split("\n")
+    res = {}
+    starts = [i for i, ln in enumerate(src) if re.match(r"^_Z\w+:", ln)]
+    for st in starts:
+        name = src[st].split(":")[0]
+        end = next(i for i in range(st, len(src)) if "s_endpgm" in src[i])
+        res[name] = scan_function(src[st:end])
+    return res
+
+
+def main():
+    files = sys.argv[1:] or [os.path.join(CSRC, f) for f in DEFAULT]
+    bad = 0
+    for f in files:
+        for name, found in scan_file(f).items():
+            print(f"{os.path.basename(f)}  {name}: {len(found)} hazard(s)")
+            for i, t, li in found[:6]:
+                print(f"    line +{i}: {t}    <- ds_read at +{li} still pending")
+            bad += len(found)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -53,12 +53,11 @@ def main():
             for rnd in range(int(os.environ.get("ROUNDS", "5"))):
                 for vkey in variants:
                     v = vkey
-                    # a variant is "<dbg>" or "<kernel><dbg>", e.g. "0", "b0", "b1"
+                    # a variant is "<dbg>" or "<kernel><dbg>", e.g. "0", "a0", "p0", "d0"
                     # "p..." = LDS-panel 3x3 kernel enabled, otherwise the im2col ring kernels
                     os.environ["VK_CONV3X3_PANEL"] = "1" if v[0] == "p" else "0"
                     os.environ["VK_CONV_DUO"] = "1" if v[0] == "d" else "0"
-                    os.environ["VK_CONV256_KERNEL"] = v[0] if v[0] in "ab" else "a"
-                    os.environ["VK_CONV256_DBG"] = v.lstrip("abpd") or "0"
+                    os.environ["VK_CONV256_DBG"] = v.lstrip("apd") or "0"
                     run()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -334,6 +334,11 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     const bool grouped = a.groups > 1;
+    if (a.pool_part) {
+        VK_REQUIRE(conv_duo_pool_ok(a) && (!a.x2 || conv_duo_dual_ok(a)), VK_EINVAL,
+                   "conv: the fused-mean form is 1x1, stride 1, f16, Cout %% 256 == 0, Ho*Wo >= 128");
+        return launch_conv_duo(a, stream);
+    }
     if (a.x2) {
         VK_REQUIRE(conv_duo_dual_ok(a), VK_EINVAL,
                    "conv: the dual-source form is 1x1, stride 1, f16, Cout %% 256 == 0, Cin and Cin2 multiples of 32");
@@ -342,11 +347,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
         if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
-        if (conv256_eligible(a)) {
-            const char *v = getenv("VK_CONV256_KERNEL");      // "a" | "b": A/B switch, re-read per call
-            if (v && v[0] == 'b' && conv256b_eligible(a)) return launch_conv256b(a, stream);
-            return launch_conv256(a, stream);
-        }
+        if (conv256_eligible(a)) return launch_conv256(a, stream);
     }
     const int es = (int)dtype_size(a.dt);
     VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32, VK_EINVAL, "conv: dtype must be f16 or f32");

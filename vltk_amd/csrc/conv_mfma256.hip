@@ -208,28 +208,20 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     VK_DSR(WF[2], w_a0 + so, 2048); \
     VK_DSR(WF[3], w_a1 + so, 2048)
 
-    // stage s+1 landed <=> at most the pieces of stages s+2, s+3 (4 each) are still outstanding
-    // (the pixel pieces of stage s+4 are only issued after this wait)
-    auto wait_next = [&](int s) {
-        if (s + 3 < S)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (s + 2 < S)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // FULL: steady state (stage s+4 exists): constant waits, no branches.  !FULL: the last stages.
-    auto stage_body = [&](auto full_c, int s, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+    // The K loop is cut into PRE(s) = rows 0-4 of stage s, ending at the in-stage barrier, and POST(s) = rows 5-7
+    // of stage s together with the first fragment reads of stage s+1.  A loop iteration is POST(s) + PRE(s+1), so
+    // every loop boundary / branch sits right after an `s_waitcnt lgkmcnt(0)`: NO hand-issued ds_read is in flight
+    // where hipcc may insert register copies (it does, at loop exits and back-edges; a copy of a register whose
+    // ds_read has not landed moves stale data: tools/check_asm_hazards.py scans the ISA for exactly that).
+    // FULL: steady state (stage s+4 exists): constant waits, no branches.  !FULL: first and last stages.
+    auto pre = [&](auto full_c, int s, const half8 (&wcur)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
         const bool more = FULL || (s + 1 < S);
         const unsigned so = (unsigned)(s & (R_NSLOT - 1)) * R_SLOT;           // this stage's slot
-        const unsigned sn = (unsigned)((s + 1) & (R_NSLOT - 1)) * R_SLOT;     // next stage's slot
-        const unsigned xs = x_a + so, xn = x_a + sn;
+        const unsigned xs = x_a + so;
         const bool rw = FULL || (s + 3 < S);      // weight pieces of stage s+3 ride on rows 0, 1
         const bool rx = FULL || (s + 4 < S);      // pixel pieces of stage s+4 ride on rows 5, 6 (after the barrier)
         // rows 0..4: read row r+3 of this stage, wait for row r (all but the 3 newest reads), 4 MFMAs.
-        // The DMA pieces ride behind MFMA groups: weights of stage s+3 on rows 0-1, pixels of stage s+4
-        // on rows 5-6 (after the barrier that frees their slot).
         VK_DSR(xw[3], xs, 3072); VK_WAIT3(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(0, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
         if (rw) req_w(s + 3, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -240,38 +232,50 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         if (rx) prep_x();                        // address arithmetic for the rows-5/6 pieces, off the critical path
         VK_DSR(xw[2], xs, 6144); VK_WAIT3(xw[3]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(3, xw[3], wcur); __builtin_amdgcn_sched_barrier(0);
         VK_DSR(xw[3], xs, 7168); VK_WAIT3(xw[0]); __builtin_amdgcn_sched_barrier(0); VK_MMA_ROW(4, xw[0], wcur); __builtin_amdgcn_sched_barrier(0);
+        // every read of stage s is issued; wait for them in straight-line code (a branch here would let hipcc
+        // set up the tied operands with copies of registers whose reads are still in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            // every read of stage s has been issued; once they are complete (lgkmcnt(0)) and every wave is
-            // here, slot (s+4)&3 == slot(s) is free, and every wave's DMA of stage s+1 has landed (vmcnt:
-            // all but the 8 pieces of stages s+2, s+3)
-            if constexpr (FULL)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // every wave's DMA of stage s+1 has landed (vmcnt: all but the pieces of stages s+2, s+3: 4 each; the
+            // pixel pieces of stage s+4 are only issued after this wait), and once every wave is here
+            // slot (s+4)&3 == slot(s) is free
+            if (FULL || s + 3 < S)
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else if (s + 2 < S)
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else
-                wait_next(s);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-            VK_READ_W(wnext, sn);
-            VK_DSR(xw[0], xn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(5, xw[1], wcur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rx) req_x(s + 4, 0);
-            VK_DSR(xw[1], xn, 1024);
-            __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(6, xw[2], wcur);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rx) req_x(s + 4, 1);
-            VK_DSR(xw[2], xn, 2048);
-            __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(7, xw[3], wcur);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
-            __builtin_amdgcn_sched_barrier(0);
-            VK_MMA_ROW(5, xw[1], wcur);
-            VK_MMA_ROW(6, xw[2], wcur);
-            VK_MMA_ROW(7, xw[3], wcur);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // stage s+1 exists and has landed: its weight fragments and first three pixel-row fragments are read under
+    // rows 5-7 of stage s; the pixel pieces of stage s+4 go into the slot PRE(s)'s barrier freed
+    auto post = [&](auto full_c, int s, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const unsigned sn = (unsigned)((s + 1) & (R_NSLOT - 1)) * R_SLOT;     // next stage's slot
+        const unsigned xn = x_a + sn;
+        const bool rx = FULL || (s + 4 < S);
+        VK_READ_W(wnext, sn);
+        VK_DSR(xw[0], xn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        VK_MMA_ROW(5, xw[1], wcur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rx) req_x(s + 4, 0);
+        VK_DSR(xw[1], xn, 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        VK_MMA_ROW(6, xw[2], wcur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rx) req_x(s + 4, 1);
+        VK_DSR(xw[2], xn, 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        VK_MMA_ROW(7, xw[3], wcur);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto last_rows = [&](const half8 (&wcur)[4]) {
+        VK_MMA_ROW(5, xw[1], wcur);
+        VK_MMA_ROW(6, xw[2], wcur);
+        VK_MMA_ROW(7, xw[3], wcur);
     };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
@@ -306,15 +310,24 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     VK_DSR(xw[0], x_a, 0);
     VK_DSR(xw[1], x_a, 1024);
     VK_DSR(xw[2], x_a, 2048);
+    pre(F_{}, 0, wa);
     int s = 0;
-    for (; s + 5 < S; s += 2) {
-        stage_body(T_{}, s, wa, wb);
-        stage_body(T_{}, s + 1, wb, wa);
+    for (; s + 6 < S; s += 2) {
+        post(T_{}, s, wa, wb);
+        pre(T_{}, s + 1, wb);
+        post(T_{}, s + 1, wb, wa);
+        pre(T_{}, s + 2, wa);
     }
-    for (; s < S; s += 2) {
-        stage_body(F_{}, s, wa, wb);
-        if (s + 1 < S) stage_body(F_{}, s + 1, wb, wa);
+    // S is even (the launcher checks): stages go in pairs, so the roles of the two weight-fragment sets are static
+    for (; s + 3 < S; s += 2) {
+        post(F_{}, s, wa, wb);
+        pre(F_{}, s + 1, wb);
+        post(F_{}, s + 1, wb, wa);
+        pre(F_{}, s + 2, wa);
     }
+    post(F_{}, s, wa, wb);
+    pre(F_{}, s + 1, wb);
+    last_rows(wb);
 #undef VK_DSR
 #undef VK_WAIT3
 #undef VK_MMA_ROW
@@ -399,7 +412,7 @@ bool conv256_eligible(const ConvArgs &a) {
     if (disabled || a.stem) return false;
     if (a.dt != VK_F16 || a.out_dt != VK_F16) return false;
     if (a.Cout % R_BN != 0 || a.ldy != a.Cout) return false;
-    if (a.Cin % 32 != 0) return false;
+    if (a.Cin % 64 != 0) return false;        // an even number of 32-channel stages (the K loop runs them in pairs)
     const long M = (long)a.N * a.Ho * a.Wo;
     return M >= 4 * R_BM;
 }

@@ -47,6 +47,8 @@ struct DuoK {
     int wrow_bytes;           // Cin * 2
     int relu;
     int m_tiles, n_tiles;
+    int *pool_part;           // [m_tiles][2][Cout][hi, lo]: exact integer column sums of the tile's rows, split at the
+                              // image boundary (y is not written)
     unsigned long *stamps;    // STAMP builds only: 8 words per workgroup (phase times, HW_ID, XCC_ID)
 };
 
@@ -150,16 +152,19 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     VKD_DSR(WF[2], w_a[0] + so, 2048);      \
     VKD_DSR(WF[3], w_a[1] + so, 2048)
 
-    // FULL: steady state (stage s+3 exists): constant waits, no branches.  !FULL: the last stages.
+    // The K loop is cut into PRE(s) = rows 0-4 of stage s, ending at the in-stage barrier, and POST(s) = rows 5-7
+    // of stage s together with the first fragment reads of stage s+1.  A loop iteration is POST(s) + PRE(s+1), so
+    // every loop boundary / branch sits right after an `s_waitcnt lgkmcnt(0)`: NO hand-issued ds_read is in flight
+    // where hipcc may insert register copies (it does, at loop exits and back-edges; a copy of a register whose
+    // ds_read has not landed moves stale data: tools/check_asm_hazards.py scans the ISA for exactly that).
+    // FULL: steady state (constant waits, no branches); !FULL: first and last stages.
     // slot = s % 3 (uniform, carried by the caller); slot of s+2 = slot of s-1, slot of s+3 = slot of s.
-    auto stage_body = [&](auto full_c, int s, int slot, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+    auto pre = [&](auto full_c, int s, int slot, const half8 (&wcur)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
-        const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // slot of stage s+1
         const int slot_p = slot == 0 ? D_NSLOT - 1 : slot - 1;       // slot of stage s+2 (= s-1)
-        const unsigned xs = x_a + (unsigned)slot * D_SLOT, xn = x_a + (unsigned)slot_n * D_SLOT;
+        const unsigned xs = x_a + (unsigned)slot * D_SLOT;
         const bool more = FULL || (s + 1 < S);
         const bool rw = FULL || (s + 2 < S);
-        const bool rx = FULL || (s + 3 < S);
         VKD_DSR(xw[3], xs, 3072); VKD_WAIT3(xw[0]); VKD_SB(); VKD_MMA_ROW(0, xw[0], wcur); VKD_SB();
         if (rw) req_w(s + 2, slot_p, 1);
         VKD_SB();
@@ -171,40 +176,49 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         VKD_SB();
         VKD_DSR(xw[2], xs, 6144); VKD_WAIT3(xw[3]); VKD_SB(); VKD_MMA_ROW(3, xw[3], wcur); VKD_SB();
         VKD_DSR(xw[3], xs, 7168); VKD_WAIT3(xw[0]); VKD_SB(); VKD_MMA_ROW(4, xw[0], wcur); VKD_SB();
+        // every read of stage s is issued; wait for them in straight-line code (a branch here would let hipcc
+        // set up the tied operands with copies of registers whose reads are still in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+        VKD_SB();
         if (more) {
-            // all reads of stage s are issued.  vmcnt: stage s+1 landed <=> only the six pieces of stage s+2
-            // (all issued by now) may be outstanding; lgkmcnt(0) + barrier: slot(s) is free for stage s+3.
+            // vmcnt: stage s+1 landed <=> only the six pieces of stage s+2 (all issued by now) may be outstanding;
+            // barrier: slot(s) is free for stage s+3
             if (FULL || s + 2 < S)
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
-            VKD_SB();
-            const unsigned sn = (unsigned)slot_n * D_SLOT;
-            VKD_READ_W(wnext, sn);
-            VKD_DSR(xw[0], xn, 0);
-            VKD_SB();
-            VKD_MMA_ROW(5, xw[1], wcur);
-            VKD_SB();
-            if (rx) req_x(s + 3, slot, 0);
-            VKD_DSR(xw[1], xn, 1024);
-            VKD_SB();
-            VKD_MMA_ROW(6, xw[2], wcur);
-            VKD_SB();
-            if (rx) req_x(s + 3, slot, 1);
-            VKD_DSR(xw[2], xn, 2048);
-            VKD_SB();
-            VKD_MMA_ROW(7, xw[3], wcur);
-            VKD_SB();
-            if (rx) req_w(s + 3, slot, 0);
-            VKD_SB();
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
-            VKD_SB();
-            VKD_MMA_ROW(5, xw[1], wcur);
-            VKD_MMA_ROW(6, xw[2], wcur);
-            VKD_MMA_ROW(7, xw[3], wcur);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        VKD_SB();
+    };
+    // stage s+1 exists and has landed (PRE(s) waited): its weight fragments and first three pixel-row fragments
+    // are read under rows 5-7 of stage s; stage s+3's first pieces go into the slot PRE(s)'s barrier freed.
+    auto post = [&](auto full_c, int s, int slot, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // slot of stage s+1
+        const unsigned xn = x_a + (unsigned)slot_n * D_SLOT, sn = (unsigned)slot_n * D_SLOT;
+        const bool rx = FULL || (s + 3 < S);
+        VKD_READ_W(wnext, sn);
+        VKD_DSR(xw[0], xn, 0);
+        VKD_SB();
+        VKD_MMA_ROW(5, xw[1], wcur);
+        VKD_SB();
+        if (rx) req_x(s + 3, slot, 0);
+        VKD_DSR(xw[1], xn, 1024);
+        VKD_SB();
+        VKD_MMA_ROW(6, xw[2], wcur);
+        VKD_SB();
+        if (rx) req_x(s + 3, slot, 1);
+        VKD_DSR(xw[2], xn, 2048);
+        VKD_SB();
+        VKD_MMA_ROW(7, xw[3], wcur);
+        VKD_SB();
+        if (rx) req_w(s + 3, slot, 0);
+        VKD_SB();
+    };
+    auto last_rows = [&](const half8 (&wcur)[4]) {
+        VKD_MMA_ROW(5, xw[1], wcur);
+        VKD_MMA_ROW(6, xw[2], wcur);
+        VKD_MMA_ROW(7, xw[3], wcur);
     };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
@@ -239,22 +253,31 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     VKD_DSR(xw[0], x_a, 0);
     VKD_DSR(xw[1], x_a, 1024);
     VKD_DSR(xw[2], x_a, 2048);
-    int s = 0, slot = 0;
     auto next_slot = [](int sl) { return sl == D_NSLOT - 1 ? 0 : sl + 1; };
-    for (; s + 4 < S; s += 2) {
-        stage_body(T_{}, s, slot, wa, wb);
+    pre(F_{}, 0, 0, wa);
+    int s = 0, slot = 0;
+    for (; s + 5 < S; s += 2) {
+        post(T_{}, s, slot, wa, wb);
         slot = next_slot(slot);
-        stage_body(T_{}, s + 1, slot, wb, wa);
+        pre(T_{}, s + 1, slot, wb);
+        post(T_{}, s + 1, slot, wb, wa);
         slot = next_slot(slot);
+        pre(T_{}, s + 2, slot, wa);
     }
-    for (; s < S; s += 2) {
-        stage_body(F_{}, s, slot, wa, wb);
+    // S is even (the launcher checks): stages go in pairs, so the roles of the two weight-fragment sets are
+    // static in every copy of the code and hipcc has no reason to shuffle them
+    for (; s + 3 < S; s += 2) {
+        post(F_{}, s, slot, wa, wb);
         slot = next_slot(slot);
-        if (s + 1 < S) {
-            stage_body(F_{}, s + 1, slot, wb, wa);
-            slot = next_slot(slot);
-        }
+        pre(F_{}, s + 1, slot, wb);
+        post(F_{}, s + 1, slot, wb, wa);
+        slot = next_slot(slot);
+        pre(F_{}, s + 2, slot, wa);
     }
+    post(F_{}, s, slot, wa, wb);
+    slot = next_slot(slot);
+    pre(F_{}, s + 1, slot, wb);
+    last_rows(wb);
 #undef VKD_DSR
 #undef VKD_WAIT3
 #undef VKD_MMA_ROW
@@ -292,6 +315,24 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
             }
         }
     };
+    // fused spatial mean: a tile (128 rows) touches at most two images when HoWo >= 128.  This thread's 16 rows
+    // of channel group k8 are summed per image from the f16 values a separate mean kernel would read back,
+    // EXACTLY: v = floor(v) + frac, both parts accumulated as integers (|floor| <= 65504, frac * 2^24 < 2^24 and
+    // exact because v has 11 significant bits), so the sum does not depend on where the tile boundaries fall
+    // and an image's features do not depend on what else is in the batch.  A non-finite value poisons its
+    // channel (sentinel -> NaN in pool_finish_kernel).
+    int ph[2][8];
+    unsigned pl[2][8];
+    unsigned badmask = 0;
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ph[sg][e] = 0;
+            pl[sg][e] = 0u;
+        }
+    const int img0 = m0 / p.HoWo;
+    const int m_split = (img0 + 1) * p.HoWo;         // first row of the tile's second image
     auto write_half = [&](int h, const half8 (&rr)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -310,7 +351,25 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
                 o[e] = (_Float16)a;
                 o[4 + e] = (_Float16)b;
             }
-            if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
+            if (p.pool_part) {
+                if (m < p.M) {
+                    const bool second = m >= m_split;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (float)o[e];
+                        const float fl = __builtin_floorf(v);
+                        const int hi = (int)fl;
+                        const unsigned lo = (unsigned)((v - fl) * 16777216.0f);
+                        ph[0][e] += second ? 0 : hi;
+                        ph[1][e] += second ? hi : 0;
+                        pl[0][e] += second ? 0u : lo;
+                        pl[1][e] += second ? lo : 0u;
+                        badmask |= (__builtin_fabsf(v) <= 65504.0f ? 0u : 1u) << ((second ? 8 : 0) + e);
+                    }
+                }
+            } else if (m < p.M) {
+                *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
+            }
         }
     };
 #define VKD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -325,6 +384,37 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     stage_half(std::integral_constant<int, 1>{});
     VKD_LDS_BARRIER();
     write_half(1, r1);
+    if (p.pool_part) {
+        // reduce the 8 row groups (tid >> 5) through LDS, then one thread per channel stores (hi, lo)
+        VKD_LDS_BARRIER();                            // staging reads done
+        int *red = reinterpret_cast<int *>(smem);     // [8 groups][2 images][256 channels][hi, lo]
+        const int grp = tid >> 5, k8 = tid & 31;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool bad = (badmask >> (sg * 8 + e)) & 1u;
+                red[(((grp * 2 + sg) * 256) + k8 * 8 + e) * 2] = bad ? 0x7fffffff : ph[sg][e];
+                red[(((grp * 2 + sg) * 256) + k8 * 8 + e) * 2 + 1] = (int)pl[sg][e];
+            }
+        VKD_LDS_BARRIER();
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+            int hi = 0;
+            unsigned lo = 0u;
+            bool bad = false;
+#pragma unroll
+            for (int gi = 0; gi < 8; ++gi) {
+                const int hv = red[(((gi * 2 + sg) * 256) + tid) * 2];
+                bad |= hv == 0x7fffffff;
+                hi += hv;
+                lo += (unsigned)red[(((gi * 2 + sg) * 256) + tid) * 2 + 1];
+            }
+            int *dst = p.pool_part + (((long)m_tile * 2 + sg) * (p.n_tiles * D_BN) + n0 + tid) * 2;
+            dst[0] = bad ? 0x7fffffff : hi;
+            dst[1] = (int)lo;
+        }
+    }
 #undef VKD_LDS_BARRIER
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -342,16 +432,55 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
 bool conv_duo_dual_ok(const ConvArgs &a) {
     return a.x2 && !a.stem && a.dt == VK_F16 && a.out_dt == VK_F16 && a.kh == 1 && a.kw == 1 && a.pad == 0 && a.stride == 1 &&
            a.groups <= 1 && a.Cout % D_BN == 0 && a.ldy == a.Cout && a.Cin % 32 == 0 && a.Cin2 % 32 == 0 && a.Cin >= 32 &&
+           (a.Cin + a.Cin2) % 64 == 0 &&
            a.Cin2 >= 32 && (long)a.N * a.H * a.W * std::max(a.Cin, a.Cin2) * 2 < (1L << 32);
 }
 
+bool conv_duo_pool_ok(const ConvArgs &a) {
+    return a.pool_part && !a.stem && a.dt == VK_F16 && a.out_dt == VK_F16 && a.kh == 1 && a.kw == 1 && a.pad == 0 &&
+           a.stride == 1 && a.groups <= 1 && a.Cout % D_BN == 0 && (a.Cin + (a.x2 ? a.Cin2 : 0)) % 64 == 0 && a.Cin >= 32 &&
+           a.Ho * a.Wo >= D_BM &&
+           a.Ho * a.Wo <= 255 &&                        // the 2^24-scaled fraction sums stay below 2^32
+           (long)a.N * a.H * a.W * a.Cin * 2 < (1L << 32);
+}
+
+size_t conv_duo_pool_part_bytes(long M, int Cout) { return (size_t)((M + D_BM - 1) / D_BM) * 2 * Cout * 2 * sizeof(int); }
+
+// out[n][c] = (exact sum of the tile partials that hold rows of image n) / HoWo, rounded once
+__global__ void pool_finish_kernel(const int *__restrict__ part, int HoWo, int Cout, float *__restrict__ out) {
+    const int n = blockIdx.x;
+    const long r0 = (long)n * HoWo, r1 = r0 + HoWo - 1;
+    const int t0 = (int)(r0 / D_BM), t1 = (int)(r1 / D_BM);
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+        long hi = 0;
+        unsigned long lo = 0;
+        bool bad = false;
+        for (int t = t0; t <= t1; ++t) {
+            const int sg = n - (int)((long)t * D_BM / HoWo);      // 0: the tile's first image, 1: its second
+            const int *q = part + (((long)t * 2 + sg) * Cout + c) * 2;
+            bad |= q[0] == 0x7fffffff;
+            hi += q[0];
+            lo += (unsigned)q[1];
+        }
+        const double sum = (double)hi + (double)lo * (1.0 / 16777216.0);
+        out[(long)n * Cout + c] = bad ? __builtin_nanf("") : (float)(sum / (double)HoWo);
+    }
+}
+
+int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(N), dim3(256), 0, stream, (const int *)part, HoWo, Cout, out);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
 bool conv_duo_eligible(const ConvArgs &a) {
+    if (a.pool_part) return conv_duo_pool_ok(a);
     if (a.x2) return conv_duo_dual_ok(a);
     const char *v = getenv("VK_CONV_DUO");               // "0" disables (A/B switch, re-read per call)
     if (v && v[0] == '0') return false;
     if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0) return false;
-    if (a.Cout % D_BN != 0 || a.ldy != a.Cout || a.Cin % 32 != 0 || a.Cin < 64) return false;
+    if (a.Cout % D_BN != 0 || a.ldy != a.Cout || a.Cin % 64 != 0) return false;
     if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets
     const long M = (long)a.N * a.Ho * a.Wo;
     if (M < 8 * D_BM) return false;
@@ -393,6 +522,8 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     k.cin2_bytes = a.x2 ? a.Cin2 * 2 : 0;
     k.split = a.Cin / 32;
     k.stages = (a.Cin + (a.x2 ? a.Cin2 : 0)) / 32;
+    VK_REQUIRE(k.stages >= 2 && k.stages % 2 == 0, VK_EINVAL, "conv_duo: K = %d is not a whole number of 64-channel pairs of stages",
+               k.stages * 32);
     k.wrow_bytes = (a.Cin + (a.x2 ? a.Cin2 : 0)) * 2;
     k.relu = a.relu;
     k.m_tiles = ceil_div(k.M, D_BM);
@@ -405,6 +536,7 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     const dim3 grid(k.m_tiles * k.n_tiles), block(256);
+    k.pool_part = (int *)a.pool_part;
     k.stamps = nullptr;
     if (const char *sf = getenv("VK_DUO_STAMPS")) {      // diagnostic: one launch, phase stamps appended to the file
         const size_t nb = (size_t)grid.x * 8 * sizeof(unsigned long);

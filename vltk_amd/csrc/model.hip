@@ -277,6 +277,13 @@ static void to_dt(const float *src, size_t n, vk_dtype dt, void *dst) {
 }
 
 // ---- arena ----
+// fp16 fast mode: `box_features.mean(dim=[2,3])` (frcnn.py:1401) is folded into the last Res5 conv3's epilogue when
+// a 128-row tile cannot span more than two RoIs (14x14 maps; RES5HALVE's 7x7 maps take the separate kernel)
+static bool fused_mean_ok(const vk_handle *h, int P) {
+    static const bool off = getenv("VK_NO_FUSED_MEAN") != nullptr;      // A/B switch
+    return !off && h->dt == VK_F16 && h->cfg.res5_halve == 0 && P * P >= 128 && P * P <= 255 && h->res5_c % 256 == 0;
+}
+
 struct Carver {
     char *base;
     size_t off = 0;
@@ -300,6 +307,7 @@ struct Plan {
     void *rpn_ws;
     size_t rpn_ws_bytes;
     void *pooled, *h_t1, *h_t2, *h_a, *h_b, *h_sc;
+    float *pool_part;        // per-tile column sums of the last Res5 conv3 (fused spatial mean), or nullptr
     float *feat;
     void *featT, *concat, *attr_hid;
     float *cls_logits, *attr_logits, *obj_prob, *attr_prob, *chosen;
@@ -375,6 +383,8 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
     p.h_a = cv.take(rows * h->res5_c * es);
     p.h_b = cv.take(rows * h->res5_c * es);
     p.h_sc = cv.take(rows * h->res5_c * es);
+    p.pool_part = nullptr;
+    if (fused_mean_ok(h, p.P)) p.pool_part = (float *)cv.take(conv_duo_pool_part_bytes((long)rows, h->res5_c));
     p.feat = (float *)cv.take((size_t)p.K * h->res5_c * sizeof(float));
     p.featT = cv.take((size_t)p.K * h->res5_c * es);
     p.concat = cv.take((size_t)p.K * (h->res5_c + h->emb_dim) * es);
@@ -394,12 +404,13 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
 
 static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int H, int W, const void *res, void *y,
                     bool relu, vk_dtype out_dt, int ldy, hipStream_t s, int *Ho = nullptr, int *Wo = nullptr,
-                    const void *x2 = nullptr, int cin2 = 0) {
+                    const void *x2 = nullptr, int cin2 = 0, float *pool_part = nullptr) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.x2 = x2;
     a.Cin2 = cin2;
+    a.pool_part = pool_part;
     a.w = L.w;
     a.bias = L.b;
     a.res = res;
@@ -427,7 +438,7 @@ static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int 
 
 // BottleneckBlock.forward frcnn.py:963-979.  x [N,H,W,cin] -> y [N,Ho,Wo,cout]
 static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, int W, void *t1, void *t2, void *sc,
-                     void *y, hipStream_t s, int *Ho, int *Wo) {
+                     void *y, hipStream_t s, int *Ho, int *Wo, float *pool_part = nullptr) {
     int h1, w1, h2, w2;
     const void *res = x;
     if (b.has_shortcut && !b.fused_shortcut) {
@@ -437,8 +448,8 @@ static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, 
     VK_TRY(run_conv(h, b.conv1, x, N, H, W, nullptr, t1, true, h->dt, 0, s, &h1, &w1));
     VK_TRY(run_conv(h, b.conv2, t1, N, h1, w1, nullptr, t2, true, h->dt, 0, s, &h2, &w2));
     if (b.fused_shortcut)      // stride-1 block: t2 and x cover the same pixels
-        return run_conv(h, b.conv3, t2, N, h2, w2, nullptr, y, true, h->dt, 0, s, Ho, Wo, x, b.shortcut.cin);
-    VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo));
+        return run_conv(h, b.conv3, t2, N, h2, w2, nullptr, y, true, h->dt, 0, s, Ho, Wo, x, b.shortcut.cin, pool_part);
+    VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo, nullptr, 0, pool_part));
     return VK_OK;
 }
 
@@ -601,6 +612,36 @@ int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M, 
     a.relu = relu;
     a.dt = a.out_dt = VK_F16;
     return launch_conv(a, (hipStream_t)stream);
+}
+
+size_t vk_conv1x1_meanpool_workspace_bytes(int N, int HW, int cout) { return conv_duo_pool_part_bytes((long)N * HW, cout); }
+
+int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_packed, const float *bias_packed,
+                        const void *residual, int cout, int relu, float *out_mean, void *workspace, size_t workspace_bytes,
+                        void *stream) {
+    VK_REQUIRE(x && out_mean && workspace && N > 0 && HW > 0, VK_EINVAL, "conv1x1_meanpool: bad arguments");
+    VK_REQUIRE(workspace_bytes >= vk_conv1x1_meanpool_workspace_bytes(N, HW, cout), VK_EINVAL, "conv1x1_meanpool: workspace too small");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.Cin = cin;
+    a.w = w_packed;
+    a.bias = bias_packed;
+    a.res = residual;
+    a.pool_part = (float *)workspace;
+    a.N = N;
+    a.H = a.Ho = 1;
+    a.W = a.Wo = HW;
+    a.Cout = cout;
+    a.ldy = cout;
+    a.kh = a.kw = 1;
+    a.stride = 1;
+    a.dil = 1;
+    a.groups = 1;
+    a.relu = relu;
+    a.dt = a.out_dt = VK_F16;
+    VK_TRY(launch_conv(a, (hipStream_t)stream));
+    return launch_pool_finish((const float *)workspace, N, HW, cout, out_mean, (hipStream_t)stream);
 }
 
 static void stem_geom(int H, int W, int *H1, int *W1, int *Hp, int *Wp) {
@@ -992,15 +1033,19 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
         void *a = p.h_a, *b2 = p.h_b;
         const void *x = p.pooled;
         int hh = P, ww = P;
-        for (auto &blk : h->res5) {
+        for (size_t bi = 0; bi < h->res5.size(); ++bi) {
             int ho, wo;
-            VK_TRY(run_block(h, blk, x, kc, hh, ww, p.h_t1, p.h_t2, p.h_sc, a, s, &ho, &wo));
+            const bool last = bi + 1 == h->res5.size();
+            VK_TRY(run_block(h, h->res5[bi], x, kc, hh, ww, p.h_t1, p.h_t2, p.h_sc, a, s, &ho, &wo, last ? p.pool_part : nullptr));
             hh = ho;
             ww = wo;
             x = a;
             std::swap(a, b2);
         }
-        VK_TRY(vk_mean_pool(x, kc, hh * ww, h->res5_c, p.feat + (size_t)k0 * h->res5_c, h->dt, s));
+        if (p.pool_part)
+            VK_TRY(launch_pool_finish(p.pool_part, kc, hh * ww, h->res5_c, p.feat + (size_t)k0 * h->res5_c, s));
+        else
+            VK_TRY(vk_mean_pool(x, kc, hh * ww, h->res5_c, p.feat + (size_t)k0 * h->res5_c, h->dt, s));
     }
     if (p.chunk >= p.K) set_stage(h, "pooled", p.pooled, h->dt, {p.K, P, P, h->res4_c});
     set_stage(h, "feature_pooled", p.feat, VK_F32, {p.K, h->res5_c});

@@ -65,6 +65,7 @@ struct ConvArgs {
     int Ho, Wo, Cout, ldy;
     int kh, kw, stride, pad, dil;
     int groups;          // 0 / 1: dense; > 1: slice-diagonal weights (vk_pack_conv_weight), Cin == Cout
+    float *pool_part;    // fused spatial mean (Res5 `.mean(dim=[2,3])`): per-tile column sums go here, y is not written
     const void *x2;      // dual-source 1x1 (conv3 + projection shortcut in one GEMM): second input [M, Cin2], K = Cin | Cin2
     int Cin2;
     int relu;
@@ -78,9 +79,10 @@ bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (1x1 convs: 128x256 tile, two workgroups per CU)
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
-bool conv_duo_dual_ok(const ConvArgs &a);                 // the dual-source form has no other kernel
-bool conv256b_eligible(const ConvArgs &a);                // conv_mfma256b.hip (128-byte LDS rows, 64-channel stages)
-int launch_conv256b(const ConvArgs &a, hipStream_t stream);
+bool conv_duo_dual_ok(const ConvArgs &a);
+bool conv_duo_pool_ok(const ConvArgs &a);                 // fused-mean form (pool_part set)
+size_t conv_duo_pool_part_bytes(long M, int Cout);
+int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream);                 // the dual-source form has no other kernel
 
 // optional per-launch event timing (set by vk_forward when enabled; thread-local)
 struct KernelTimer {
