@@ -28,14 +28,24 @@ def conv_gflop_per_image(R):
     return 292.4 + 40.0 + 5.857 * R + 0.03554 * R
 
 
-def pmc_traffic(batch, proposals):
+KERNEL_NAMES = {   # kernel_timing() bucket -> (rocprofv3 kernel name, description)
+    "conv_mfma256": ("conv_mfma256_kernel", "256x256 LDS-ring implicit-GEMM conv"),
+    "conv3x3_panel": ("conv3x3_panel_kernel", "3x3 conv from an LDS-resident input panel, 256x256 tile"),
+    "conv_duo": ("conv_duo_kernel", "1x1 conv / dual-source GEMM, 128x256 tile, two workgroups per CU"),
+    "conv_mfma_f16": ("conv_mfma_kernel", "128x{64,128} tile conv"),
+    "conv_mfma_f16_f32out": ("conv_mfma_kernel", "128x{64,128} tile conv, f32 out"),
+    "other": ("conv_mfma_kernel", "stem / strict-mode convs"),
+}
+
+
+def pmc_traffic(batch, proposals, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent or for another workload."""
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent or for another workload/kernel."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         d = json.load(open(path))
-        if d.get("batch") == batch and d.get("proposals") == proposals:
+        if d.get("batch") == batch and d.get("proposals") == proposals and d.get("kernel") == kernel:
             return d["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -125,7 +135,9 @@ def main():
     assert out["roi_features"].shape[0] == world * B
 
     if rank == 0:
-        dom = kt["conv_mfma256"]
+        dom_key = max(kt, key=lambda k: kt[k]["ms"])          # the kernel with the most GPU time in the timed region
+        dom = kt[dom_key]
+        dom_name, dom_desc = KERNEL_NAMES[dom_key]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         all_ms = sum(v["ms"] for v in kt.values())
         all_fl = sum(v["flops"] for v in kt.values())
@@ -139,12 +151,16 @@ def main():
                                    f"through the Res5 head, max {a.detections} detections/img, seeded synthetic weights",
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(B, a.proposals),
+                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(B, a.proposals, dom_name),
                          "alg_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
-                         "kernel": "conv_mfma256_kernel (256x256 LDS-ring implicit-GEMM conv, f16 in / f32 acc; all launches of the timed region)",
+                         "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
                          "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals), 1),
+                         "per_kernel": {KERNEL_NAMES[k][0] + ("" if k in ("conv_mfma256", "conv3x3_panel", "conv_duo") else ":" + k):
+                                        {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
+                                         "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
+                                        for k, v in kt.items() if v["ms"] > 0},
                          "all_conv_kernels": {"ms_per_step": round(all_ms / a.steps, 3),
                                               "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
                                               "share_of_step": round(all_ms / (dt * 1e3), 4)}},

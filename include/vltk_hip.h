@@ -154,11 +154,12 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
 
 /* Per-kernel timing of the forward's convolution launches (HIP events on the launch stream around
  * every launch; read after the forward's own end-of-call synchronisation, accumulated until reset).
- * bucket 0: conv_mfma256_kernel (256x256 LDS-ring tile; the dominant kernel)   1: conv_mfma_kernel f16->f16 (128x{64,128} tile)
- * bucket 2: conv_mfma_kernel f16->f32 out (RPN heads, predictor GEMMs)          3: f32 strict-mode convs / stem
- * launches[4], ms[4], flops[4] (algorithmic 2*M*Cout*K of the launches), bytes[4] (algorithmic HBM bytes:
+ * bucket 0: conv_mfma256_kernel (256x256 LDS-ring tile)          1: conv_mfma_kernel f16->f16 (128x{64,128} tile)
+ * bucket 2: conv_mfma_kernel f16->f32 out (RPN heads, predictor)  3: f32 strict-mode convs / stem
+ * bucket 4: conv3x3_panel_kernel (3x3, LDS-resident input panel)  5: conv_duo_kernel (1x1, 128x256 tile, two per CU)
+ * launches[6], ms[6], flops[6] (algorithmic 2*M*Cout*K of the launches), bytes[6] (algorithmic HBM bytes:
  * input + output (+ residual) + weights, each once). */
-#define VK_NUM_KERNEL_BUCKETS 4
+#define VK_NUM_KERNEL_BUCKETS 6
 int vk_enable_kernel_timing(vk_handle *h, int enable);
 int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 

@@ -55,6 +55,11 @@ def main():
         print(f"  {nm:16s} median {np.median(d):7.2f} us   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}")
     d = ts[:, 4] - ts[:, 0]
     print(f"  {'whole workgroup':16s} median {np.median(d):7.2f} us")
+    S = int(rows[0, 12])
+    loop, vm, bar = rows[:, 9].astype(np.float64), rows[:, 10].astype(np.float64), rows[:, 11].astype(np.float64)
+    clk = np.median(loop / np.maximum((ts[:, 2] - ts[:, 1]) * 1e-6, 1e-12)) / 1e9
+    print(f"  mfma loop (wave 0): {np.median(loop) / S:7.0f} core cycles per stage ({S} stages, 512 = MFMA-bound), clock {clk:.2f} GHz;"
+          f" waiting for DMA {np.median(vm / loop):.1%}, at the barrier {np.median(bar / loop):.1%}")
     # co-residency: workgroups by (XCC, SE, SH, CU)
     cu = ((rows[:, 7] & 0xF) << 8) | ((rows[:, 6] >> 8) & 0xFF)
     by = collections.defaultdict(list)

@@ -448,7 +448,7 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * 9 * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 9, 1,
+        tm->recs.push_back({4, 2.0 * (double)k.M * a.Cout * 9 * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 9, 1,
                             2.0 * ((double)k.M * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * 9 * a.Cin)});
     }
     return VK_OK;

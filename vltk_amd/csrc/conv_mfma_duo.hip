@@ -49,13 +49,17 @@ struct DuoK {
     int m_tiles, n_tiles;
     int *pool_part;           // [m_tiles][2][Cout][hi, lo]: exact integer column sums of the tile's rows, split at the
                               // image boundary (y is not written)
-    unsigned long *stamps;    // STAMP builds only: 8 words per workgroup (phase times, HW_ID, XCC_ID)
+    unsigned long *stamps;    // STAMP builds only: 12 words per workgroup (phase times, HW_ID, XCC_ID, cycle sums)
 };
 
 constexpr int D_BM = 128, D_BN = 256, D_NSLOT = 3;
-constexpr int D_XB = D_BM * 64;              // 8 KiB
-constexpr int D_SLOT = D_XB + D_BN * 64;     // 24 KiB
-constexpr int D_SMEM = D_NSLOT * D_SLOT;     // 72 KiB
+constexpr int D_XB = D_BM * 64;              // 8 KiB: one stage of pixel rows
+constexpr int D_WB = D_BN * 64;              // 16 KiB: one stage of weight rows
+// LDS = [pixel ring: XS slots][weight ring: 3 slots].  XS = 4 (80 KiB each, two workgroups fill the CU's 160 KiB
+// exactly) requests pixel rows one stage earlier than weights; measured identical to XS = 3 on every shape
+// (interleaved runs, one device), and in-kernel cycle stamps agree: a wave waits for DMA only 3.5-7.5 % of its
+// MFMA loop (tools/duo_stamps.py), so the product uses XS = 3.
+constexpr int d_smem(int XS) { return XS * D_XB + D_NSLOT * D_WB; }
 
 #define VKD_GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
@@ -63,10 +67,14 @@ constexpr int D_SMEM = D_NSLOT * D_SLOT;     // 72 KiB
 
 // STAMP: diagnostic build (VK_DUO_STAMPS=<file>): wave 0 records s_memrealtime at the phase boundaries into a
 // buffer nothing else reads (cdna guide section 7, in-kernel stamps); never used by the product path.
-template <bool STAMP>
+// DBG 1 (timing-only STAMP build, WRONG results): weight pieces not requested (2 instead of 6 LDS-DMA instructions per
+// wave and stage): 1638 -> 1279 cycles per stage on Res5 conv1, i.e. ~90 cycles of issue per LDS-DMA piece; the same
+// four loads as compiler-tracked global_load_dwordx4 into registers were slower (1869), so the pieces stay DMA
+template <bool STAMP, int XS, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
+    constexpr int D_WBASE = XS * D_XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long ts[5];
+    unsigned long ts[5], cyc_vm = 0, cyc_bar = 0, cyc0 = 0, cyc1 = 0;
     if constexpr (STAMP) ts[0] = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware (bijective) workgroup -> tile map: consecutive tiles (same pixel rows, next channel block)
@@ -103,17 +111,19 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     }
     const unsigned wsrc0 = (unsigned)(n0 + wave * 64 + lrow) * (unsigned)p.wrow_bytes + lchunk * 16;
     const unsigned wstep = 16u * p.wrow_bytes;
-    auto req_x = [&](int stage, int slot, int i) {
+    auto req_x = [&](int stage, int i) {                             // pixel ring slot = stage % XS
+        const int slot = XS == 4 ? (stage & 3) : stage % XS;
         const bool second = stage >= p.split;                        // uniform
         unsigned a = second ? a2_off[i] : a_off[i];
         asm volatile("" : "+v"(a));     // opaque: keeps the add in the loop instead of a register per (stage, piece)
         const char *base = second ? p.x2 : p.x;
-        VKD_GLDS16(base + (a + (unsigned)(stage - (second ? p.split : 0)) * 64u), smem + slot * D_SLOT + (wave * 2 + i) * 1024);
+        VKD_GLDS16(base + (a + (unsigned)(stage - (second ? p.split : 0)) * 64u), smem + slot * D_XB + (wave * 2 + i) * 1024);
     };
     auto req_w = [&](int stage, int slot, int i) {
         unsigned a = wsrc0;
         asm volatile("" : "+v"(a));
-        VKD_GLDS16(p.w + (a + i * wstep + (unsigned)stage * 64u), smem + slot * D_SLOT + D_XB + (wave * 4 + i) * 1024);
+        if constexpr (DBG == 1) return;
+        VKD_GLDS16(p.w + (a + i * wstep + (unsigned)stage * 64u), smem + D_WBASE + slot * D_WB + (wave * 4 + i) * 1024);
     };
 
     // ---- fragment read addresses ----
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
         const int wrow = wave * 64 + (j >> 2) * 8 + par * 4 + (j & 3);                   // + (ni>>1)*32 rows
-        w_a[par] = lds0 + D_XB + wrow * 64 + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
+        w_a[par] = lds0 + D_WBASE + wrow * 64 + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
     }
 
     floatx4 acc[8][4];
@@ -161,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     // slot = s % 3 (uniform, carried by the caller); slot of s+2 = slot of s-1, slot of s+3 = slot of s.
     auto pre = [&](auto full_c, int s, int slot, const half8 (&wcur)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
-        const int slot_p = slot == 0 ? D_NSLOT - 1 : slot - 1;       // slot of stage s+2 (= s-1)
-        const unsigned xs = x_a + (unsigned)slot * D_SLOT;
+        const int slot_p = slot == 0 ? D_NSLOT - 1 : slot - 1;       // weight slot of stage s+2 (= s-1)
+        const unsigned xs = x_a + (unsigned)(XS == 4 ? (s & 3) : s % XS) * D_XB;
         const bool more = FULL || (s + 1 < S);
         const bool rw = FULL || (s + 2 < S);
         VKD_DSR(xw[3], xs, 3072); VKD_WAIT3(xw[0]); VKD_SB(); VKD_MMA_ROW(0, xw[0], wcur); VKD_SB();
@@ -181,10 +191,27 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
         VKD_SB();
         if (more) {
-            // vmcnt: stage s+1 landed <=> only the six pieces of stage s+2 (all issued by now) may be outstanding;
-            // barrier: slot(s) is free for stage s+3
-            if (FULL || s + 2 < S)
+            // vmcnt: stage s+1 landed <=> only what was issued after its last piece may be outstanding: the two
+            // pixel pieces of stage s-1+XS and the four weight pieces of stage s+2; barrier: the slots of stage s
+            // are free
+            if constexpr (STAMP) {     // where the stage's slack goes: DMA wait vs barrier wait (core-clock cycles)
+                unsigned long ta, tb, tc;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ta)::"memory");
+                if (FULL || s - 1 + XS < S)
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (s + 2 < S)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb)::"memory");
+                asm volatile("s_barrier" ::: "memory");
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tc)::"memory");
+                cyc_vm += tb - ta;
+                cyc_bar += tc - tb;
+            } else if (FULL || s - 1 + XS < S)
                 asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else if (s + 2 < S)
+                asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -194,25 +221,26 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     // are read under rows 5-7 of stage s; stage s+3's first pieces go into the slot PRE(s)'s barrier freed.
     auto post = [&](auto full_c, int s, int slot, const half8 (&wcur)[4], half8 (&wnext)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
-        const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // slot of stage s+1
-        const unsigned xn = x_a + (unsigned)slot_n * D_SLOT, sn = (unsigned)slot_n * D_SLOT;
-        const bool rx = FULL || (s + 3 < S);
+        const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // weight slot of stage s+1
+        const unsigned xn = x_a + (unsigned)(XS == 4 ? ((s + 1) & 3) : (s + 1) % XS) * D_XB, sn = (unsigned)slot_n * D_WB;
+        const bool rx = FULL || (s + XS < S);
+        const bool rw0 = FULL || (s + 3 < S);
         VKD_READ_W(wnext, sn);
         VKD_DSR(xw[0], xn, 0);
         VKD_SB();
         VKD_MMA_ROW(5, xw[1], wcur);
         VKD_SB();
-        if (rx) req_x(s + 3, slot, 0);
+        if (rx) req_x(s + XS, 0);
         VKD_DSR(xw[1], xn, 1024);
         VKD_SB();
         VKD_MMA_ROW(6, xw[2], wcur);
         VKD_SB();
-        if (rx) req_x(s + 3, slot, 1);
+        if (rx) req_x(s + XS, 1);
         VKD_DSR(xw[2], xn, 2048);
         VKD_SB();
         VKD_MMA_ROW(7, xw[3], wcur);
         VKD_SB();
-        if (rx) req_w(s + 3, slot, 0);
+        if (rw0) req_w(s + 3, slot, 0);
         VKD_SB();
     };
     auto last_rows = [&](const half8 (&wcur)[4]) {
@@ -223,32 +251,32 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
 
-    // ---- prologue: stages 0 and 1 completely, and the first three pieces of stage 2 ----
-    int issued = 0;
+    // ---- prologue: pixel rows of stages 0..XS-1, weights of stages 0 and 1 and the first weight piece of stage 2;
+    // all of it is waited for (the pieces are in flight together, so this costs one latency) ----
+#pragma unroll
+    for (int st = 0; st < XS; ++st) {
+        if (st < S) {
+            req_x(st, 0);
+            req_x(st, 1);
+        }
+    }
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
         if (st < S) {
-            req_x(st, st, 0);
-            req_x(st, st, 1);
             req_w(st, st, 0);
-            issued += 3;
             if (st < 2) {
                 req_w(st, st, 1);
                 req_w(st, st, 2);
                 req_w(st, st, 3);
-                issued += 3;
             }
         }
     }
-    // stage 0 (the 6 oldest pieces) must have landed
-    if (issued == 15)
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if (issued == 12)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if constexpr (STAMP) ts[1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) {
+        ts[1] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc0)::"memory");
+    }
     VKD_READ_W(wa, 0u);
     VKD_DSR(xw[0], x_a, 0);
     VKD_DSR(xw[1], x_a, 1024);
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     auto next_slot = [](int sl) { return sl == D_NSLOT - 1 ? 0 : sl + 1; };
     pre(F_{}, 0, 0, wa);
     int s = 0, slot = 0;
-    for (; s + 5 < S; s += 2) {
+    for (; s + XS + 1 < S && s + 5 < S; s += 2) {
         post(T_{}, s, slot, wa, wb);
         slot = next_slot(slot);
         pre(T_{}, s + 1, slot, wb);
@@ -286,7 +314,10 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
 
     // ---- epilogue: + bias (+ residual) (ReLU) -> f16 through LDS, two halves of 64 rows x 256 channels ----
     asm volatile("s_barrier" ::: "memory");          // every wave has finished reading its fragments
-    if constexpr (STAMP) ts[2] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (STAMP) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc1)::"memory");
+        ts[2] = __builtin_amdgcn_s_memrealtime();
+    }
     floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
     auto load_res = [&](int h, half8 (&rr)[8]) {
 #pragma unroll
@@ -420,11 +451,15 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[4] = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned long *o = p.stamps + (long)bid * 8;
+            unsigned long *o = p.stamps + (long)bid * 12;
             for (int i = 0; i < 5; ++i) o[i] = ts[i];
             o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
             o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
             o[7] = t;
+            o[8] = cyc1 - cyc0;                                    // MFMA loop, core-clock cycles
+            o[9] = cyc_vm;                                         // of which: waiting for the next stage's DMA
+            o[10] = cyc_bar;                                       // of which: waiting for the other waves
+            o[11] = p.stages;
         }
     }
 }
@@ -493,10 +528,12 @@ bool conv_duo_eligible(const ConvArgs &a) {
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, D_SMEM));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, D_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<false, 3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true, 3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true, 3, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
         attr_set = true;
     }
     DuoK k;
@@ -539,29 +576,33 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     k.pool_part = (int *)a.pool_part;
     k.stamps = nullptr;
     if (const char *sf = getenv("VK_DUO_STAMPS")) {      // diagnostic: one launch, phase stamps appended to the file
-        const size_t nb = (size_t)grid.x * 8 * sizeof(unsigned long);
+        const size_t nb = (size_t)grid.x * 12 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
-        hipLaunchKernelGGL(conv_duo_kernel<true>, grid, block, D_SMEM, stream, k);
+        const int dbg = getenv("VK_DUO_DBG") ? atoi(getenv("VK_DUO_DBG")) : 0;
+        if (dbg == 1)
+            hipLaunchKernelGGL((conv_duo_kernel<true, 3, 1>), grid, block, d_smem(3), stream, k);
+        else
+            hipLaunchKernelGGL((conv_duo_kernel<true, 3>), grid, block, d_smem(3), stream, k);
         VK_CHECK_HIP(hipStreamSynchronize(stream));
-        std::vector<unsigned long> h((size_t)grid.x * 8);
+        std::vector<unsigned long> h((size_t)grid.x * 12);
         VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
         VK_CHECK_HIP(hipFree(k.stamps));
         if (FILE *f = fopen(sf, "a")) {
             fprintf(f, "# launch M=%d cout=%d cin=%d grid=%u\n", k.M, a.Cout, a.Cin, grid.x);
             for (unsigned b = 0; b < grid.x; ++b) {
                 fprintf(f, "%u", b);
-                for (int i = 0; i < 8; ++i) fprintf(f, " %lu", h[(size_t)b * 8 + i]);
+                for (int i = 0; i < 12; ++i) fprintf(f, " %lu", h[(size_t)b * 12 + i]);
                 fprintf(f, "\n");
             }
             fclose(f);
         }
     } else
-        hipLaunchKernelGGL(conv_duo_kernel<false>, grid, block, D_SMEM, stream, k);
+        hipLaunchKernelGGL((conv_duo_kernel<false, 3>), grid, block, d_smem(3), stream, k);
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
-        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, K, 1, a.stride,
+        tm->recs.push_back({5, 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, K, 1, a.stride,
                             2.0 * ((double)a.N * a.H * a.W * K + (double)k.M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * K)});
     }
     return VK_OK;

@@ -96,10 +96,10 @@ struct KernelTimer {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
-    int64_t launches[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
-    double ms[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
-    double flops[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};
-    double bytes[VK_NUM_KERNEL_BUCKETS] = {0, 0, 0, 0};   // algorithmic: input + output (+ residual) + weights, once each
+    int64_t launches[VK_NUM_KERNEL_BUCKETS] = {};
+    double ms[VK_NUM_KERNEL_BUCKETS] = {};
+    double flops[VK_NUM_KERNEL_BUCKETS] = {};
+    double bytes[VK_NUM_KERNEL_BUCKETS] = {};   // algorithmic: input + output (+ residual) + weights, once each
     hipEvent_t get();
     void collect();   // after the stream has been synchronised
     ~KernelTimer();
