@@ -207,20 +207,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     // (no panel prefetch, weight requests stop when t + 6 >= 9*CS, no step after tap 8).
     // ODD = parity of cs (stages run in pairs, so it is known at compile time): panel buffer = ODD, and the
     // weight slot of step t = 9*cs + J is (3*ODD + J) % 6.
-    auto step = [&](auto last_c, auto odd_c, auto j_c, int cs, unsigned xa, unsigned &xa_next, const half8 (&wcur)[4],
-                    half8 (&wnext)[4]) {
-        constexpr bool LAST = decltype(last_c)::value;
-        constexpr int ODD = decltype(odd_c)::value ? 1 : 0;
+    // A step is cut at its barrier into PRE (rows 0-4, then every LDS read of the step is complete) and POST (rows
+    // 5-7 together with the first fragment reads of the next step); the loop iterates POST(t-1) + PRE(t), so NO
+    // hand-issued ds_read is in flight at a loop boundary, where hipcc may copy fragment registers
+    // (tools/check_asm_hazards.py; see conv_mfma256.hip).
+    auto tap_mask = [&](auto j_c) -> unsigned {
         constexpr int J = decltype(j_c)::value;
-        constexpr int SLOT = (3 * ODD + J) % P_NW;            // == t % 6; also the slot of step t + 6
         // opaque copy of the mask word BEFORE the shift: otherwise hipcc hoists either the 72 (tap, row-tile)
         // lane masks (SGPR pairs) or the 9 shifted words out of the loop and spills them
         unsigned tw = J < 4 ? vm0 : (J < 8 ? vm1 : vm2);
         asm volatile("" : "+v"(tw));
-        const unsigned tm = tw >> ((J & 3) * 8);
+        return tw >> ((J & 3) * 8);
+    };
+    auto pre = [&](auto last_c, auto odd_c, auto j_c, unsigned xa, unsigned &xa_next, const half8 (&wcur)[4]) {
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr int ODD = decltype(odd_c)::value;
+        constexpr int J = decltype(j_c)::value;
+        const unsigned tm = tap_mask(j_c);
         constexpr bool has_next = !(LAST && J == 8);
-        constexpr bool issue_w = !LAST || (J + P_NW < 9);
-        constexpr bool issue_p = !LAST && (J < PP);
         // address of the next step's fragments (next tap; next stage's panel after tap 8)
         if constexpr (has_next) xa_next = (J == 8) ? x_addr_of(1 - ODD, 0) : x_addr_of(ODD, J + 1);
         VKP_DSR(xw[3], xa, 3072); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(0, xw[0], wcur, tm); VKP_SB();
@@ -228,58 +232,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         VKP_DSR(xw[1], xa, 5120); VKP_WAIT3(xw[2]); VKP_SB(); VKP_MMA_ROW(2, xw[2], wcur, tm); VKP_SB();
         VKP_DSR(xw[2], xa, 6144); VKP_WAIT3(xw[3]); VKP_SB(); VKP_MMA_ROW(3, xw[3], wcur, tm); VKP_SB();
         VKP_DSR(xw[3], xa, 7168); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+        VKP_SB();
         if constexpr (has_next) {
-            // all reads of this step are issued.  vmcnt: everything older than the pieces issued in the last
-            // P_NW-2 steps has landed = weights of step t+1 (and, before tap 0, the next stage's panel);
-            // lgkmcnt(0) + barrier: weight slot (t % 6) is free for step t+6, the other panel buffer is free
-            // once the stage ends.
+            // vmcnt: everything older than the pieces issued in the last P_NW-2 steps has landed = weights of step
+            // t+1 (and, before tap 0, the next stage's panel); barrier: weight slot (t % 6) is free for step t+6,
+            // the other panel buffer is free once the stage ends.
             constexpr int OUT = LAST ? last_w_in_window<J>() : 2 * (P_NW - 2) + panel_in_window<J, PP>();
             vm_wait<OUT>();
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
-            VKP_SB();
-            constexpr unsigned so = (unsigned)((SLOT + 1) % P_NW) * P_WSLOT;
-            VKP_READ_W(wnext, so);
-            VKP_DSR(xw[0], xa_next, 0);
-            VKP_SB();
-            VKP_MMA_ROW(5, xw[1], wcur, tm);
-            VKP_SB();
-            if constexpr (issue_p) req_panel(cs + 1, J);
-            if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 0);
-            VKP_DSR(xw[1], xa_next, 1024);
-            VKP_SB();
-            VKP_MMA_ROW(6, xw[2], wcur, tm);
-            VKP_SB();
-            if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 1);
-            VKP_DSR(xw[2], xa_next, 2048);
-            VKP_SB();
-            VKP_MMA_ROW(7, xw[3], wcur, tm);
-            VKP_SB();
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]));
-            VKP_SB();
-            VKP_MMA_ROW(5, xw[1], wcur, tm);
-            VKP_MMA_ROW(6, xw[2], wcur, tm);
-            VKP_MMA_ROW(7, xw[3], wcur, tm);
+            asm volatile("s_barrier" ::: "memory");
         }
+        VKP_SB();
     };
-    // nine taps of one stage; the weight-fragment sets alternate, so a stage flips their roles: `flip` says
-    // which set is current at tap 0
-#define VKP_TAP(LASTC, JJ, CUR, NXT)                                                                 \
-    step(LASTC, flip_c, std::integral_constant<int, JJ>{}, cs, xa, xan, CUR, NXT);                    \
-    xa = xan;
-    auto stage9 = [&](auto last_c, auto flip_c, int cs, unsigned &xa) {
-        constexpr bool FLIP = decltype(flip_c)::value;
-        unsigned xan = 0;
-        if constexpr (!FLIP) {
-            VKP_TAP(last_c, 0, wa, wb) VKP_TAP(last_c, 1, wb, wa) VKP_TAP(last_c, 2, wa, wb) VKP_TAP(last_c, 3, wb, wa)
-            VKP_TAP(last_c, 4, wa, wb) VKP_TAP(last_c, 5, wb, wa) VKP_TAP(last_c, 6, wa, wb) VKP_TAP(last_c, 7, wb, wa)
-            VKP_TAP(last_c, 8, wa, wb)
-        } else {
-            VKP_TAP(last_c, 0, wb, wa) VKP_TAP(last_c, 1, wa, wb) VKP_TAP(last_c, 2, wb, wa) VKP_TAP(last_c, 3, wa, wb)
-            VKP_TAP(last_c, 4, wb, wa) VKP_TAP(last_c, 5, wa, wb) VKP_TAP(last_c, 6, wb, wa) VKP_TAP(last_c, 7, wa, wb)
-            VKP_TAP(last_c, 8, wb, wa)
-        }
+    auto post = [&](auto last_c, auto odd_c, auto j_c, int cs, unsigned xa_next, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+        constexpr bool LAST = decltype(last_c)::value;
+        constexpr int ODD = decltype(odd_c)::value;
+        constexpr int J = decltype(j_c)::value;
+        static_assert(!(LAST && J == 8), "the final step has no POST");
+        constexpr int SLOT = (3 * ODD + J) % P_NW;            // == t % 6; also the slot of step t + 6
+        const unsigned tm = tap_mask(j_c);
+        constexpr bool issue_w = !LAST || (J + P_NW < 9);
+        constexpr bool issue_p = !LAST && (J < PP);
+        constexpr unsigned so = (unsigned)((SLOT + 1) % P_NW) * P_WSLOT;
+        VKP_READ_W(wnext, so);
+        VKP_DSR(xw[0], xa_next, 0);
+        VKP_SB();
+        VKP_MMA_ROW(5, xw[1], wcur, tm);
+        VKP_SB();
+        if constexpr (issue_p) req_panel(cs + 1, J);
+        if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 0);
+        VKP_DSR(xw[1], xa_next, 1024);
+        VKP_SB();
+        VKP_MMA_ROW(6, xw[2], wcur, tm);
+        VKP_SB();
+        if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 1);
+        VKP_DSR(xw[2], xa_next, 2048);
+        VKP_SB();
+        VKP_MMA_ROW(7, xw[3], wcur, tm);
+        VKP_SB();
     };
+    // u = 9*ODD + J numbers the 18 steps of a pair of stages; step u works from fragment set u % 2
+    auto wset = [&](auto u_c) -> half8(&)[4] {
+        if constexpr (decltype(u_c)::value % 2 == 0)
+            return wa;
+        else
+            return wb;
+    };
+#define VKP_IC(V) std::integral_constant<int, (V)> {}
+    // POST(u-1) + PRE(u) inside the pair that starts at stage cs; LP / LC: is step u-1 / u in the final stage
+#define VKP_UNIT(LP, LC, U)                                                                                          \
+    post(LP, VKP_IC(((U) - 1) / 9), VKP_IC(((U) - 1) % 9), cs + ((U) - 1) / 9, xan, wset(VKP_IC((U) - 1)), wset(VKP_IC(U)));  \
+    xa = xan;                                                                                                        \
+    pre(LC, VKP_IC((U) / 9), VKP_IC((U) % 9), xa, xan, wset(VKP_IC(U)));
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
 
@@ -293,20 +297,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     }
     vm_wait<2 * (P_NW - 1)>();
     asm volatile("s_barrier" ::: "memory");
-    unsigned xa = x_addr_of(0, 0);
+    unsigned xa = x_addr_of(0, 0), xan = 0;
     VKP_READ_W(wa, 0u);
     VKP_DSR(xw[0], xa, 0);
     VKP_DSR(xw[1], xa, 1024);
     VKP_DSR(xw[2], xa, 2048);
-    // CS is even: stages go in pairs (the second stage of a pair starts with the fragment sets flipped)
+    pre(F_{}, VKP_IC(0), VKP_IC(0), xa, xan, wa);
+    // CS is even: stages go in pairs (18 steps, so the roles of the two fragment sets repeat per pair)
     int cs = 0;
     for (; cs + 2 < CS; cs += 2) {
-        stage9(F_{}, F_{}, cs, xa);
-        stage9(F_{}, T_{}, cs + 1, xa);
+        VKP_UNIT(F_{}, F_{}, 1) VKP_UNIT(F_{}, F_{}, 2) VKP_UNIT(F_{}, F_{}, 3) VKP_UNIT(F_{}, F_{}, 4) VKP_UNIT(F_{}, F_{}, 5)
+        VKP_UNIT(F_{}, F_{}, 6) VKP_UNIT(F_{}, F_{}, 7) VKP_UNIT(F_{}, F_{}, 8) VKP_UNIT(F_{}, F_{}, 9) VKP_UNIT(F_{}, F_{}, 10)
+        VKP_UNIT(F_{}, F_{}, 11) VKP_UNIT(F_{}, F_{}, 12) VKP_UNIT(F_{}, F_{}, 13) VKP_UNIT(F_{}, F_{}, 14) VKP_UNIT(F_{}, F_{}, 15)
+        VKP_UNIT(F_{}, F_{}, 16) VKP_UNIT(F_{}, F_{}, 17)
+        // last step of this pair, first step of the next one
+        post(F_{}, VKP_IC(1), VKP_IC(8), cs + 1, xan, wb, wa);
+        xa = xan;
+        pre(F_{}, VKP_IC(0), VKP_IC(0), xa, xan, wa);
     }
-    stage9(F_{}, F_{}, cs, xa);
-    stage9(T_{}, T_{}, cs + 1, xa);
-#undef VKP_TAP
+    // final pair: its second stage is the LAST one
+    VKP_UNIT(F_{}, F_{}, 1) VKP_UNIT(F_{}, F_{}, 2) VKP_UNIT(F_{}, F_{}, 3) VKP_UNIT(F_{}, F_{}, 4) VKP_UNIT(F_{}, F_{}, 5)
+    VKP_UNIT(F_{}, F_{}, 6) VKP_UNIT(F_{}, F_{}, 7) VKP_UNIT(F_{}, F_{}, 8) VKP_UNIT(F_{}, T_{}, 9) VKP_UNIT(T_{}, T_{}, 10)
+    VKP_UNIT(T_{}, T_{}, 11) VKP_UNIT(T_{}, T_{}, 12) VKP_UNIT(T_{}, T_{}, 13) VKP_UNIT(T_{}, T_{}, 14) VKP_UNIT(T_{}, T_{}, 15)
+    VKP_UNIT(T_{}, T_{}, 16) VKP_UNIT(T_{}, T_{}, 17)
+    {
+        const unsigned tm = tap_mask(VKP_IC(8));
+        VKP_MMA_ROW(5, xw[1], wb, tm);
+        VKP_MMA_ROW(6, xw[2], wb, tm);
+        VKP_MMA_ROW(7, xw[3], wb, tm);
+    }
+#undef VKP_UNIT
+#undef VKP_IC
 #undef VKP_DSR
 #undef VKP_WAIT3
 #undef VKP_MMA_ROW
