@@ -23,8 +23,10 @@ PEAK_F16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 
-def conv_gflop_per_image(R):
-    """SURVEY.md §8d algorithmic work (2*MAC) per 800x1333 image, R101-C4: backbone + RPN head + Res5 head."""
+def conv_gflop_per_image(R, arch="r101"):
+    """SURVEY.md §8d algorithmic work (2*MAC) per 800x1333 image: backbone + RPN head + Res5 head (+ predictor)."""
+    if arch == "x152":
+        return 943.5 + 40.0 + 11.25 * R + 0.03554 * R
     return 292.4 + 40.0 + 5.857 * R + 0.03554 * R
 
 
@@ -84,6 +86,8 @@ def main():
     ap.add_argument("--detections", type=int, default=100)
     ap.add_argument("--head-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arch", default="r101", choices=["r101", "x152"],
+                    help="r101 = the BASELINE workload (configs[1]); x152 = ResNeXt-152 32x8d (SURVEY.md 8d config c4, extra)")
     a = ap.parse_args()
 
     import torch
@@ -99,7 +103,8 @@ def main():
 
     from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
     from vltk_amd.parallel import gather_outputs
-    cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}")
+    arch = dict(depth=152, num_groups=32, width_per_group=8) if a.arch == "x152" else {}
+    cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}", **arch)
     sd = make_state_dict(cfg, seed=1234)
     model = FRCNN(cfg, precision="fp16", device=f"cuda:{local_rank}").load_state_dict(sd).eval()
     if a.head_chunk >= 0:
@@ -146,7 +151,8 @@ def main():
             "value": round(world * B * a.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: ResNet-101-C4 fp16 (the reference has no FPN: SURVEY.md D1), "
+            "config": {"workload": ("configs[1]: ResNet-101-C4 fp16" if a.arch == "r101" else "EXTRA (SURVEY.md 8d c4): ResNeXt-152 32x8d C4 fp16") +
+                                   " (the reference has no FPN: SURVEY.md D1), "
                                    f"{B} synthetic 800x1333 images per GPU per step, R={a.proposals} RPN proposals "
                                    f"through the Res5 head, max {a.detections} detections/img, seeded synthetic weights",
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
@@ -156,7 +162,7 @@ def main():
                          "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
-                         "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals), 1),
+                         "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals, a.arch), 1),
                          "per_kernel": {KERNEL_NAMES[k][0] + ("" if k in ("conv_mfma256", "conv3x3_panel", "conv_duo") else ":" + k):
                                         {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
