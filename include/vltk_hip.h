@@ -36,7 +36,9 @@ extern "C" {
 #define VK_EHIP 5        /* HIP runtime failure                                          -> RuntimeError */
 #define VK_ENOMEM 6
 
-typedef enum { VK_F32 = 0, VK_F16 = 1, VK_I64 = 2, VK_I32 = 3 } vk_dtype;
+typedef enum { VK_F32 = 0, VK_F16 = 1, VK_I64 = 2, VK_I32 = 3, VK_BF16 = 4 } vk_dtype;
+/* epilogue activation of vk_conv2d / vk_linear (the `relu` argument): */
+typedef enum { VK_ACT_NONE = 0, VK_ACT_RELU = 1, VK_ACT_GELU = 2 /* erf form */, VK_ACT_TANH = 3 } vk_act;
 
 #define VK_MAX_ANCHOR_DIM 8
 #define VK_MAX_NMS_THRESH 8
@@ -204,6 +206,26 @@ size_t vk_conv1x1_meanpool_workspace_bytes(int N, int HW, int cout);
 int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_packed, const float *bias_packed,
                         const void *residual, int cout, int relu, float *out_mean,
                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- N3: LXMERT-style cross-modality encoder ops (transformers LxmertModel, the consumer the reference feeds:
+ * vltk/legacy/legacy_train.py:30-39; restated from transformers/models/lxmert/modeling_lxmert.py v5.15) ---- */
+
+/* nn.Linear (+ residual) (+ activation): y[M, ldy] = act(x[M,K] . W^T + bias + residual).  W packed by
+ * vk_pack_conv_weight(w [N,K,1,1], NULL, bias, ...); K a whole number of 128-byte K-tiles; dt f32 | f16 | bf16. */
+int vk_linear(const void *x, long M, int K, const void *w_packed, const float *bias_packed, const void *residual,
+              void *y, int N, int ldy, int act, vk_dtype dt, vk_dtype out_dt, void *stream);
+/* y = scale * LayerNorm(x) (+ y when accumulate): LxmertAttentionOutput / LxmertOutput :269-342 (eps 1e-12),
+ * LxmertVisualFeatureEncoder `(LN(a) + LN(b)) / 2` :468-476 as two calls with scale 0.5. */
+int vk_layernorm(const void *x, int ldx, const float *gamma, const float *beta, void *y, int ldy, int M, int C,
+                 float eps, float scale, int accumulate, vk_dtype dt, void *stream);
+/* LxmertEmbeddings.forward :191-214: LayerNorm(word[ids] + position[arange(L)] + token_type[tt]); tables in dt. */
+int vk_embed_layernorm(const int64_t *input_ids, const int64_t *token_type_ids, int B, int L, const void *word,
+                       const void *position, const void *token_type, const float *gamma, const float *beta,
+                       void *y, int C, float eps, vk_dtype dt, void *stream);
+/* LxmertAttention.forward :238-266 after the three projections: out[b, i, h*d:(h+1)*d] =
+ * softmax_j(q_i . k_j / sqrt(d) + mask[b, j]) . v_j; q [B*Lq, ldq], k / v [B*Lk, ld*], heads side by side in a row. */
+int vk_attention(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const float *mask,
+                 void *out, int ldo, int B, int heads, int Lq, int Lk, int d, vk_dtype dt, void *stream);
 
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
 int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);

@@ -13,4 +13,7 @@ def __getattr__(name):
     if name == "FRCNN":
         from .frcnn import FRCNN
         return FRCNN
+    if name == "LxmertEncoder":          # N3: the encoder that consumes the extractor's output
+        from .lxmert import LxmertEncoder
+        return LxmertEncoder
     raise AttributeError(name)

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvltk_hip.so")
 
 VK_OK, VK_EINVAL, VK_ENOTIMPL, VK_ENONFINITE, VK_EWEIGHTS, VK_EHIP, VK_ENOMEM = range(7)
-VK_F32, VK_F16, VK_I64, VK_I32 = 0, 1, 2, 3
+VK_F32, VK_F16, VK_I64, VK_I32, VK_BF16 = 0, 1, 2, 3, 4
+VK_ACT_NONE, VK_ACT_RELU, VK_ACT_GELU, VK_ACT_TANH = 0, 1, 2, 3
 VK_MAX_ANCHOR_DIM = 8
 VK_MAX_NMS_THRESH = 8
 
@@ -88,6 +89,10 @@ SIGNATURES = {
     "vk_conv1x1_dual": (_I, [_P, _I, _P, _I, C.c_long, _P, _P, _P, _P, _I, _I, _P]),
     "vk_conv1x1_meanpool_workspace_bytes": (_SZ, [_I, _I, _I]),
     "vk_conv1x1_meanpool": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
+    "vk_linear": (_I, [_P, C.c_long, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "vk_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P]),
+    "vk_embed_layernorm": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
+    "vk_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_conv2d": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "vk_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),

@@ -408,7 +408,7 @@ static int panel_pp(const ConvArgs &a) {
 bool conv3x3_panel_eligible(const ConvArgs &a) {
     const char *v = getenv("VK_CONV3X3_PANEL");          // "0" disables (A/B switch, re-read per call)
     if (v && v[0] == '0') return false;
-    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
+    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != a.dil) return false;
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cin % 64 != 0 || a.Cin < 128) return false;
     if (panel_pp(a) == 0) return false;

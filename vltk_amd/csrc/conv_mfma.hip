@@ -27,6 +27,7 @@ namespace vk {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,6 +59,11 @@ struct Frag<_Float16> {
     static constexpr int KSTEPS = 2;  // 64 halfs per K-tile, 32 per MFMA
 };
 template <>
+struct Frag<__bf16> {
+    typedef bf16x8 type;
+    static constexpr int KSTEPS = 2;  // 64 bf16 per K-tile, 32 per MFMA
+};
+template <>
 struct Frag<float> {
     typedef float type;
     static constexpr int KSTEPS = 8;  // 32 floats per K-tile, 4 per MFMA
@@ -65,6 +71,9 @@ struct Frag<float> {
 
 __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ floatx4 mfma(bf16x8 a, bf16x8 b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ floatx4 mfma(float a, float b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -76,6 +85,11 @@ template <>
 __device__ __forceinline__ half8 lds_frag<_Float16>(const char *tile, int row, int ks, int g) {
     int chunk = ks * 4 + g;
     return *reinterpret_cast<const half8 *>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+template <>
+__device__ __forceinline__ bf16x8 lds_frag<__bf16>(const char *tile, int row, int ks, int g) {
+    int chunk = ks * 4 + g;
+    return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 template <>
 __device__ __forceinline__ float lds_frag<float>(const char *tile, int row, int ks, int g) {
@@ -92,6 +106,13 @@ __device__ __forceinline__ void store8<_Float16>(char *dst, const float (&v)[8])
     *reinterpret_cast<half8 *>(dst) = h;
 }
 template <>
+__device__ __forceinline__ void store8<__bf16>(char *dst, const float (&v)[8]) {
+    bf16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (__bf16)v[i];     // round to nearest even
+    *reinterpret_cast<bf16x8 *>(dst) = h;
+}
+template <>
 __device__ __forceinline__ void store8<float>(char *dst, const float (&v)[8]) {
     floatx4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
     reinterpret_cast<floatx4 *>(dst)[0] = a;
@@ -103,6 +124,12 @@ __device__ __forceinline__ void load8(const char *src, float (&v)[8]);
 template <>
 __device__ __forceinline__ void load8<_Float16>(const char *src, float (&v)[8]) {
     half8 h = *reinterpret_cast<const half8 *>(src);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+template <>
+__device__ __forceinline__ void load8<__bf16>(const char *src, float (&v)[8]) {
+    bf16x8 h = *reinterpret_cast<const bf16x8 *>(src);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
 }
@@ -295,9 +322,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
                 v[e] = acc[mi][2 * qn][e] + b[e] + rr[mi][e];
                 v[4 + e] = acc[mi][2 * qn + 1][e] + b[4 + e] + rr[mi][4 + e];
             }
-            if (p.relu) {
+            if (p.relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (p.relu == 2) {      // GELU, erf form (transformers ACT2FN["gelu"])
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752f));
+            } else if (p.relu == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             }
             if (m < p.M) store8<OutT>(p.y + ((long)m * p.ldy + co) * (long)sizeof(OutT), v);
         }
@@ -350,7 +383,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         if (conv256_eligible(a)) return launch_conv256(a, stream);
     }
     const int es = (int)dtype_size(a.dt);
-    VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32, VK_EINVAL, "conv: dtype must be f16 or f32");
+    VK_REQUIRE(a.dt == VK_F16 || a.dt == VK_F32 || a.dt == VK_BF16, VK_EINVAL, "conv: dtype must be f16, bf16 or f32");
     VK_REQUIRE(a.out_dt == a.dt || a.out_dt == VK_F32, VK_EINVAL, "conv: out dtype must equal dtype or be f32");
     ConvK k;
     k.x = (const char *)a.x;
@@ -405,6 +438,11 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     const bool narrow = a.Cout <= 64 || a.stem || grouped;
     k.n_tiles = ceil_div(a.Cout, narrow ? 64 : 128);
     const bool f32out = (a.out_dt == VK_F32);
+    if (a.dt == VK_BF16) {      // LXMERT-style encoder GEMMs (N3): same tiling, v_mfma_f32_16x16x32_bf16
+        VK_REQUIRE(!a.stem, VK_EINVAL, "conv: no bf16 stem");
+        if (f32out) return narrow ? launch_t<__bf16, float, 64, false>(k, stream) : launch_t<__bf16, float, 128, false>(k, stream);
+        return narrow ? launch_t<__bf16, __bf16, 64, false>(k, stream) : launch_t<__bf16, __bf16, 128, false>(k, stream);
+    }
     if (a.dt == VK_F16) {
         if (a.stem) return launch_t<_Float16, _Float16, 64, true>(k, stream);
         if (f32out) return narrow ? launch_t<_Float16, float, 64, false>(k, stream)

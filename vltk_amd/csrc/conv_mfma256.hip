@@ -410,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
 bool conv256_eligible(const ConvArgs &a) {
     static const bool disabled = getenv("VK_DISABLE_CONV256") != nullptr;
     if (disabled || a.stem) return false;
+    if (a.relu > 1) return false;             // only the 128-tile kernel has the GELU / tanh epilogues
     if (a.dt != VK_F16 || a.out_dt != VK_F16) return false;
     if (a.Cout % R_BN != 0 || a.ldy != a.Cout) return false;
     if (a.Cin % 64 != 0) return false;        // an even number of 32-channel stages (the K loop runs them in pairs)

@@ -513,7 +513,7 @@ bool conv_duo_eligible(const ConvArgs &a) {
     if (a.x2) return conv_duo_dual_ok(a);
     const char *v = getenv("VK_CONV_DUO");               // "0" disables (A/B switch, re-read per call)
     if (v && v[0] == '0') return false;
-    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16) return false;
+    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0) return false;
     if (a.Cout % D_BN != 0 || a.ldy != a.Cout || a.Cin % 64 != 0) return false;
     if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets

@@ -1,0 +1,209 @@
+// Non-GEMM kernels of the LXMERT-style cross-modality encoder (the reference feeds the
+// extractor's [B,36,2048] features + [B,36,4] boxes to transformers' LxmertModel, vltk/legacy/legacy_train.py:30-39).
+// Restated from transformers/models/lxmert/modeling_lxmert.py (v5.15): LxmertEmbeddings :179-214, LxmertAttention
+// :217-266, LayerNorm uses eps 1e-12, LxmertVisualFeatureEncoder :452-476.  The linear layers run on the MFMA GEMM of
+// conv_mfma.hip (bf16 / f16 / f32); everything here is HBM- or latency-bound and computes in fp32.
+//
+//   layernorm_kernel   y = scale * LayerNorm(x) (+ y)      one wave per row
+//   embed_ln_kernel    LayerNorm(word[id] + position[l] + token_type[tt])
+//   attention_kernel   softmax(Q K^T / sqrt(d) + mask) V per (batch, head); K and V of one head live in LDS
+#include "vk_common.h"
+
+namespace vk {
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T *p) { return (float)*p; }
+template <typename T>
+__device__ __forceinline__ void stf(T *p, float v) { *p = (T)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int LN_MAX_PER_LANE = 32;      // rows up to 2048 elements
+
+// x [M, C] (row stride ldx), y [M, C] (row stride ldy).  Mean / biased variance in fp32 over the stored values,
+// (x - mean) / sqrt(var + eps) * gamma + beta like at::native::layer_norm.
+template <typename T, bool EMBED>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, T *__restrict__ y, int ldy, int M, int C,
+                                                       float eps, float scale, int accumulate,
+                                                       // EMBED: x = word table, rows picked by ids; + position + token type
+                                                       const int64_t *__restrict__ ids, const int64_t *__restrict__ tts,
+                                                       const T *__restrict__ pos, const T *__restrict__ typ, int L) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float v[LN_MAX_PER_LANE];
+    const int n = (C + 63) / 64;
+    float s = 0.f;
+    const T *xr = EMBED ? x + (long)ids[row] * ldx : x + (long)row * ldx;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        float t = 0.f;
+        if (i < n && c < C) {
+            t = ldf(xr + c);
+            if (EMBED) t = t + ldf(pos + (long)(row % L) * C + c) + ldf(typ + (long)tts[row] * C + c);
+        }
+        v[i] = t;
+        s += t;
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (i < n && c < C) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (i < n && c < C) {
+            float o = ((v[i] - mean) * rstd * gamma[c] + beta[c]) * scale;
+            T *yp = y + (long)row * ldy + c;
+            if (accumulate) o += ldf(yp);
+            stf(yp, o);
+        }
+    }
+}
+
+// One workgroup per (batch b, head h); thread t owns query row t (Lq <= 256).  K, V of the head are staged in LDS
+// as fp32 [Lk][d]; scores, soft-max and the weighted sum are fp32 (the reference matmuls in the model dtype and
+// soft-maxes in it too; the bf16-emulating oracle restates THIS kernel's rounding points: inputs and output only).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ k, int ldk,
+                                                       const T *__restrict__ v, int ldv, const float *__restrict__ mask,
+                                                       T *__restrict__ out, int ldo, int heads, int Lq, int Lk, int d, float scale) {
+    extern __shared__ float sm[];
+    float *ks = sm, *vs = sm + Lk * d, *qs = sm + 2 * Lk * d;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    for (int i = threadIdx.x; i < Lk * d; i += blockDim.x) {
+        const int r = i / d, c = i - r * d;
+        ks[i] = ldf(k + ((long)b * Lk + r) * ldk + h * d + c);
+        vs[i] = ldf(v + ((long)b * Lk + r) * ldv + h * d + c);
+    }
+    for (int i = threadIdx.x; i < Lq * d; i += blockDim.x) {
+        const int r = i / d, c = i - r * d;
+        qs[i] = ldf(q + ((long)b * Lq + r) * ldq + h * d + c);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= Lq) return;
+    const float *qr = qs + t * d;
+    // pass 1: scores and their maximum (kept in LDS-free form: recomputed in pass 2 to stay register-light)
+    float mx = -INFINITY;
+    for (int j = 0; j < Lk; ++j) {
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s += qr[c] * ks[j * d + c];
+        s = s * scale + (mask ? mask[(long)b * Lk + j] : 0.f);
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    float acc[128];
+#pragma unroll
+    for (int c = 0; c < 128; ++c) acc[c] = 0.f;
+    for (int j = 0; j < Lk; ++j) {
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s += qr[c] * ks[j * d + c];
+        s = s * scale + (mask ? mask[(long)b * Lk + j] : 0.f);
+        const float p = expf(s - mx);
+        den += p;
+#pragma unroll
+        for (int c = 0; c < 128; ++c)
+            if (c < d) acc[c] += p * vs[j * d + c];
+    }
+    const float inv = 1.0f / den;
+    T *orow = out + ((long)b * Lq + t) * ldo + h * d;
+#pragma unroll
+    for (int c = 0; c < 128; ++c)
+        if (c < d) stf(orow + c, acc[c] * inv);
+}
+
+template <typename T>
+static int ln_launch(const void *x, int ldx, const float *g, const float *b, void *y, int ldy, int M, int C, float eps, float scale,
+                     int accumulate, const int64_t *ids, const int64_t *tts, const void *pos, const void *typ, int L, hipStream_t s) {
+    const dim3 grid((M + 3) / 4), block(256);
+    if (ids)
+        hipLaunchKernelGGL((layernorm_kernel<T, true>), grid, block, 0, s, (const T *)x, ldx, g, b, (T *)y, ldy, M, C, eps, scale, accumulate,
+                           ids, tts, (const T *)pos, (const T *)typ, L);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<T, false>), grid, block, 0, s, (const T *)x, ldx, g, b, (T *)y, ldy, M, C, eps, scale, accumulate,
+                           nullptr, nullptr, nullptr, nullptr, 1);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+static int ln_dispatch(vk_dtype dt, const void *x, int ldx, const float *g, const float *b, void *y, int ldy, int M, int C, float eps,
+                       float scale, int accumulate, const int64_t *ids, const int64_t *tts, const void *pos, const void *typ, int L,
+                       hipStream_t s) {
+    VK_REQUIRE(M > 0 && C > 0 && C <= 64 * LN_MAX_PER_LANE, VK_EINVAL, "layernorm: C=%d must be in 1..%d", C, 64 * LN_MAX_PER_LANE);
+    switch (dt) {
+        case VK_F32: return ln_launch<float>(x, ldx, g, b, y, ldy, M, C, eps, scale, accumulate, ids, tts, pos, typ, L, s);
+        case VK_F16: return ln_launch<_Float16>(x, ldx, g, b, y, ldy, M, C, eps, scale, accumulate, ids, tts, pos, typ, L, s);
+        case VK_BF16: return ln_launch<__bf16>(x, ldx, g, b, y, ldy, M, C, eps, scale, accumulate, ids, tts, pos, typ, L, s);
+        default: break;
+    }
+    VK_REQUIRE(false, VK_EINVAL, "layernorm: dtype must be f32, f16 or bf16");
+    return VK_EINVAL;
+}
+
+}  // namespace vk
+
+using namespace vk;
+
+extern "C" {
+
+int vk_layernorm(const void *x, int ldx, const float *gamma, const float *beta, void *y, int ldy, int M, int C, float eps, float scale,
+                 int accumulate, vk_dtype dt, void *stream) {
+    VK_REQUIRE(x && gamma && beta && y, VK_EINVAL, "layernorm: null argument");
+    return ln_dispatch(dt, x, ldx, gamma, beta, y, ldy, M, C, eps, scale, accumulate, nullptr, nullptr, nullptr, nullptr, 1,
+                       (hipStream_t)stream);
+}
+
+int vk_embed_layernorm(const int64_t *input_ids, const int64_t *token_type_ids, int B, int L, const void *word, const void *position,
+                       const void *token_type, const float *gamma, const float *beta, void *y, int C, float eps, vk_dtype dt,
+                       void *stream) {
+    VK_REQUIRE(input_ids && token_type_ids && word && position && token_type && gamma && beta && y, VK_EINVAL, "embed: null argument");
+    return ln_dispatch(dt, word, C, gamma, beta, y, C, B * L, C, eps, 1.0f, 0, input_ids, token_type_ids, position, token_type, L,
+                       (hipStream_t)stream);
+}
+
+int vk_attention(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const float *mask, void *out, int ldo, int B,
+                 int heads, int Lq, int Lk, int d, vk_dtype dt, void *stream) {
+    VK_REQUIRE(q && k && v && out, VK_EINVAL, "attention: null argument");
+    VK_REQUIRE(B > 0 && heads > 0 && Lq >= 1 && Lq <= 256 && Lk >= 1 && d >= 1 && d <= 128, VK_EINVAL,
+               "attention: need 1 <= Lq <= 256, d <= 128 (got Lq=%d Lk=%d d=%d)", Lq, Lk, d);
+    const size_t smem = (size_t)(2 * Lk + Lq) * d * sizeof(float);
+    VK_REQUIRE(smem <= 160 * 1024, VK_EINVAL, "attention: (2*Lk+Lq)*d=%d floats do not fit LDS", (2 * Lk + Lq) * d);
+    const float scale = 1.0f / sqrtf((float)d);
+    const dim3 grid(B * heads), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define VK_ATT(T)                                                                                                        \
+    do {                                                                                                                 \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<T>),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL(attention_kernel<T>, grid, block, smem, s, (const T *)q, ldq, (const T *)k, ldk, (const T *)v, ldv, mask, \
+                           (T *)out, ldo, heads, Lq, Lk, d, scale);                                                     \
+    } while (0)
+    switch (dt) {
+        case VK_F32: VK_ATT(float); break;
+        case VK_F16: VK_ATT(_Float16); break;
+        case VK_BF16: VK_ATT(__bf16); break;
+        default: VK_REQUIRE(false, VK_EINVAL, "attention: dtype must be f32, f16 or bf16");
+    }
+#undef VK_ATT
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+}  // extern "C"

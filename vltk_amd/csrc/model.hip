@@ -271,6 +271,16 @@ static void to_dt(const float *src, size_t n, vk_dtype dt, void *dst) {
     if (dt == VK_F16) {
         _Float16 *d = (_Float16 *)dst;
         for (size_t i = 0; i < n; ++i) d[i] = (_Float16)src[i];
+    } else if (dt == VK_BF16) {          // round to nearest even, like torch's float -> bfloat16
+        uint16_t *d = (uint16_t *)dst;
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t u;
+            memcpy(&u, &src[i], 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u)
+                d[i] = (uint16_t)((u >> 16) | 0x40);              // NaN stays NaN
+            else
+                d[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
     } else {
         memcpy(dst, src, n * sizeof(float));
     }
@@ -486,7 +496,7 @@ size_t vk_packed_weight_bytes(int cout, int cin, int kh, int kw, int groups, vk_
 
 int vk_pack_conv_weight(const float *w, const float *bn, const float *bias, int cout, int cin, int kh, int kw, int groups,
                         vk_dtype dt, void *w_packed, float *bias_packed) {
-    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "pack: dtype must be f16 or f32");
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32 || dt == VK_BF16, VK_EINVAL, "pack: dtype must be f16, bf16 or f32");
     VK_REQUIRE(groups >= 1, VK_EINVAL, "pack: groups=%d", groups);
     const int sw = vk_conv_slice_channels(cin, groups);     // K channels per tap in the packed row (== cin when dense)
     VK_REQUIRE(sw > 0, VK_EINVAL, "pack: cin=%d / groups=%d must be a power of two", cin, groups);
@@ -611,6 +621,32 @@ int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M, 
     a.groups = 1;
     a.relu = relu;
     a.dt = a.out_dt = VK_F16;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+int vk_linear(const void *x, long M, int K, const void *w_packed, const float *bias_packed, const void *residual, void *y, int N, int ldy,
+              int act, vk_dtype dt, vk_dtype out_dt, void *stream) {
+    VK_REQUIRE(x && w_packed && bias_packed && y && M > 0 && M < (1L << 31), VK_EINVAL, "linear: bad arguments");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.Cin = K;
+    a.w = w_packed;
+    a.bias = bias_packed;
+    a.res = residual;
+    a.y = y;
+    a.N = 1;
+    a.H = a.Ho = 1;
+    a.W = a.Wo = (int)M;
+    a.Cout = N;
+    a.ldy = ldy;
+    a.kh = a.kw = 1;
+    a.stride = 1;
+    a.dil = 1;
+    a.groups = 1;
+    a.relu = act;
+    a.dt = dt;
+    a.out_dt = out_dt;
     return launch_conv(a, (hipStream_t)stream);
 }
 

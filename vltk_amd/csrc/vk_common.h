@@ -43,6 +43,7 @@ static inline size_t dtype_size(vk_dtype dt) {
         case VK_F16: return 2;
         case VK_I64: return 8;
         case VK_I32: return 4;
+        case VK_BF16: return 2;
     }
     return 0;
 }
