@@ -28,8 +28,23 @@
 
 namespace vk {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// element type of the operands / output: f16 (detector) or bf16 (the encoder's GEMMs); accumulation is fp32 either way
+template <typename ET>
+struct DuoT;
+template <>
+struct DuoT<_Float16> {
+    typedef half8 vec;
+    static __device__ __forceinline__ floatx4 mfma(vec a, vec b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct DuoT<__bf16> {
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ floatx4 mfma(vec a, vec b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
 
 struct DuoK {
     const char *x;
@@ -70,8 +85,11 @@ constexpr int d_smem(int XS) { return XS * D_XB + D_NSLOT * D_WB; }
 // DBG 1 (timing-only STAMP build, WRONG results): weight pieces not requested (2 instead of 6 LDS-DMA instructions per
 // wave and stage): 1638 -> 1279 cycles per stage on Res5 conv1, i.e. ~90 cycles of issue per LDS-DMA piece; the same
 // four loads as compiler-tracked global_load_dwordx4 into registers were slower (1869), so the pieces stay DMA
-template <bool STAMP, int XS, int DBG = 0>
+// GELU: the erf-form GELU epilogue (encoder FFN) is a separate instantiation: sixteen inlined erff() in the epilogue of
+// every build cost the detector 16 % (instruction footprint), measured
+template <typename ET, bool STAMP, int XS, int DBG = 0, bool GELU = false>
 __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
+    typedef typename DuoT<ET>::vec vec8;
     constexpr int D_WBASE = XS * D_XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long ts[5], cyc_vm = 0, cyc_bar = 0, cyc0 = 0, cyc1 = 0;
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 wa[4], wb[4], xw[4];
+    vec8 wa[4], wb[4], xw[4];
     const int S = p.stages;
 
     // hand-issued fragment reads with counted waits (see conv_mfma256.hip: hipcc would wait lgkmcnt(0) at
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     do {                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                               \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                               \
-            __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ni], XR, acc[MI][ni], 0, 0, 0);                \
+            DuoT<ET>::mfma(WF[ni], XR, acc[MI][ni]);                                              \
         __builtin_amdgcn_s_setprio(0);                                                               \
     } while (0)
 #define VKD_READ_W(WF, so)                  \
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     // ds_read has not landed moves stale data: tools/check_asm_hazards.py scans the ISA for exactly that).
     // FULL: steady state (constant waits, no branches); !FULL: first and last stages.
     // slot = s % 3 (uniform, carried by the caller); slot of s+2 = slot of s-1, slot of s+3 = slot of s.
-    auto pre = [&](auto full_c, int s, int slot, const half8 (&wcur)[4]) {
+    auto pre = [&](auto full_c, int s, int slot, const vec8 (&wcur)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
         const int slot_p = slot == 0 ? D_NSLOT - 1 : slot - 1;       // weight slot of stage s+2 (= s-1)
         const unsigned xs = x_a + (unsigned)(XS == 4 ? (s & 3) : s % XS) * D_XB;
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
     };
     // stage s+1 exists and has landed (PRE(s) waited): its weight fragments and first three pixel-row fragments
     // are read under rows 5-7 of stage s; stage s+3's first pieces go into the slot PRE(s)'s barrier freed.
-    auto post = [&](auto full_c, int s, int slot, const half8 (&wcur)[4], half8 (&wnext)[4]) {
+    auto post = [&](auto full_c, int s, int slot, const vec8 (&wcur)[4], vec8 (&wnext)[4]) {
         constexpr bool FULL = decltype(full_c)::value;
         const int slot_n = slot == D_NSLOT - 1 ? 0 : slot + 1;       // weight slot of stage s+1
         const unsigned xn = x_a + (unsigned)(XS == 4 ? ((s + 1) & 3) : (s + 1) % XS) * D_XB, sn = (unsigned)slot_n * D_WB;
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         if (rw0) req_w(s + 3, slot, 0);
         VKD_SB();
     };
-    auto last_rows = [&](const half8 (&wcur)[4]) {
+    auto last_rows = [&](const vec8 (&wcur)[4]) {
         VKD_MMA_ROW(5, xw[1], wcur);
         VKD_MMA_ROW(6, xw[2], wcur);
         VKD_MMA_ROW(7, xw[3], wcur);
@@ -319,15 +337,15 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         ts[2] = __builtin_amdgcn_s_memrealtime();
     }
     floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
-    auto load_res = [&](int h, half8 (&rr)[8]) {
+    auto load_res = [&](int h, vec8 (&rr)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int it = tid + 256 * i, row = it >> 5, k8 = it & 31;
             const int m = min(m0 + h * 64 + row, p.M - 1);
             if (p.res)
-                rr[i] = *reinterpret_cast<const half8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
+                rr[i] = *reinterpret_cast<const vec8 *>(p.res + ((long)m * p.ldy + n0 + k8 * 8) * 2);
             else
-                rr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                rr[i] = vec8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
     auto stage_half = [&](auto h_c) {
@@ -364,23 +382,26 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         }
     const int img0 = m0 / p.HoWo;
     const int m_split = (img0 + 1) * p.HoWo;         // first row of the tile's second image
-    auto write_half = [&](int h, const half8 (&rr)[8]) {
+    auto write_half = [&](int h, const vec8 (&rr)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int it = tid + 256 * i, row = it >> 5, k8 = it & 31;
             const int m = m0 + h * 64 + row;
             const floatx4 v0 = stg[row * 64 + ((2 * k8) ^ (row & 7))];
             const floatx4 v1 = stg[row * 64 + ((2 * k8 + 1) ^ (row & 7))];
-            half8 o;
+            vec8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = v0[e] + (float)rr[i][e], b = v1[e] + (float)rr[i][4 + e];
-                if (p.relu) {
+                if constexpr (GELU) {              // erf form (transformers ACT2FN["gelu"])
+                    a = 0.5f * a * (1.0f + erff(a * 0.70710678118654752f));
+                    b = 0.5f * b * (1.0f + erff(b * 0.70710678118654752f));
+                } else if (p.relu) {
                     a = a > 0.f ? a : 0.f;
                     b = b > 0.f ? b : 0.f;
                 }
-                o[e] = (_Float16)a;
-                o[4 + e] = (_Float16)b;
+                o[e] = (ET)a;
+                o[4 + e] = (ET)b;
             }
             if (p.pool_part) {
                 if (m < p.M) {
@@ -399,12 +420,12 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
                     }
                 }
             } else if (m < p.M) {
-                *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
+                *reinterpret_cast<vec8 *>(p.y + ((long)m * p.ldy + n0 + k8 * 8) * 2) = o;
             }
         }
     };
 #define VKD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    half8 r0[8], r1[8];
+    vec8 r0[8], r1[8];
     load_res(0, r0);
     stage_half(std::integral_constant<int, 0>{});
     VKD_LDS_BARRIER();
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
 }
 
 bool conv_duo_dual_ok(const ConvArgs &a) {
-    return a.x2 && !a.stem && a.dt == VK_F16 && a.out_dt == VK_F16 && a.kh == 1 && a.kw == 1 && a.pad == 0 && a.stride == 1 &&
+    return a.x2 && !a.stem && (a.dt == VK_F16 || a.dt == VK_BF16) && a.out_dt == a.dt && a.kh == 1 && a.kw == 1 && a.pad == 0 && a.stride == 1 &&
            a.groups <= 1 && a.Cout % D_BN == 0 && a.ldy == a.Cout && a.Cin % 32 == 0 && a.Cin2 % 32 == 0 && a.Cin >= 32 &&
            (a.Cin + a.Cin2) % 64 == 0 &&
            a.Cin2 >= 32 && (long)a.N * a.H * a.W * std::max(a.Cin, a.Cin2) * 2 < (1L << 32);
@@ -513,7 +534,8 @@ bool conv_duo_eligible(const ConvArgs &a) {
     if (a.x2) return conv_duo_dual_ok(a);
     const char *v = getenv("VK_CONV_DUO");               // "0" disables (A/B switch, re-read per call)
     if (v && v[0] == '0') return false;
-    if (a.stem || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
+    if (a.stem || (a.dt != VK_F16 && a.dt != VK_BF16) || a.out_dt != a.dt) return false;
+    if (a.relu > 2 || (a.relu == 2 && a.dt != VK_BF16)) return false;     // GELU epilogue: bf16 build only; no tanh
     if (a.kh != 1 || a.kw != 1 || a.pad != 0) return false;
     if (a.Cout % D_BN != 0 || a.ldy != a.Cout || a.Cin % 64 != 0) return false;
     if ((long)a.N * a.H * a.W * a.Cin * 2 >= (1L << 32)) return false;   // 32-bit DMA offsets
@@ -528,11 +550,15 @@ bool conv_duo_eligible(const ConvArgs &a) {
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<false, 3>),
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, false, 3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true, 3>),
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<__bf16, false, 3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<true, 3, 1>),
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<__bf16, false, 3, 0, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, true, 3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, true, 3, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
         attr_set = true;
     }
@@ -580,9 +606,9 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
         const int dbg = getenv("VK_DUO_DBG") ? atoi(getenv("VK_DUO_DBG")) : 0;
         if (dbg == 1)
-            hipLaunchKernelGGL((conv_duo_kernel<true, 3, 1>), grid, block, d_smem(3), stream, k);
+            hipLaunchKernelGGL((conv_duo_kernel<_Float16, true, 3, 1>), grid, block, d_smem(3), stream, k);
         else
-            hipLaunchKernelGGL((conv_duo_kernel<true, 3>), grid, block, d_smem(3), stream, k);
+            hipLaunchKernelGGL((conv_duo_kernel<_Float16, true, 3>), grid, block, d_smem(3), stream, k);
         VK_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long> h((size_t)grid.x * 12);
         VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
@@ -597,7 +623,12 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
             fclose(f);
         }
     } else
-        hipLaunchKernelGGL((conv_duo_kernel<false, 3>), grid, block, d_smem(3), stream, k);
+        if (a.dt == VK_BF16 && a.relu == 2)
+            hipLaunchKernelGGL((conv_duo_kernel<__bf16, false, 3, 0, true>), grid, block, d_smem(3), stream, k);
+        else if (a.dt == VK_BF16)
+            hipLaunchKernelGGL((conv_duo_kernel<__bf16, false, 3>), grid, block, d_smem(3), stream, k);
+        else
+            hipLaunchKernelGGL((conv_duo_kernel<_Float16, false, 3>), grid, block, d_smem(3), stream, k);
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));

@@ -73,56 +73,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x,
     }
 }
 
-// One workgroup per (batch b, head h); thread t owns query row t (Lq <= 256).  K, V of the head are staged in LDS
-// as fp32 [Lk][d]; scores, soft-max and the weighted sum are fp32 (the reference matmuls in the model dtype and
-// soft-maxes in it too; the bf16-emulating oracle restates THIS kernel's rounding points: inputs and output only).
+// One workgroup per (batch b, head h).  Q, K, V of the head are staged in LDS as fp32 (rows padded by one float so
+// that column walks do not collide on a bank); 256 threads share the Lq x Lk scores, one wave per row does the
+// soft-max, then the threads share the Lq x d outputs.  Scores, soft-max and the weighted sum are fp32 (the
+// reference matmuls and soft-maxes in the model dtype; the bf16-emulating oracle restates THIS kernel's rounding
+// points: inputs and output only).
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ k, int ldk,
                                                        const T *__restrict__ v, int ldv, const float *__restrict__ mask,
                                                        T *__restrict__ out, int ldo, int heads, int Lq, int Lk, int d, float scale) {
     extern __shared__ float sm[];
-    float *ks = sm, *vs = sm + Lk * d, *qs = sm + 2 * Lk * d;
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    for (int i = threadIdx.x; i < Lk * d; i += blockDim.x) {
+    const int dp = d + 1, lp = Lk + 1;
+    float *qs = sm, *ks = qs + Lq * dp, *vs = ks + Lk * dp, *ps = vs + Lk * d;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    for (int i = tid; i < Lk * d; i += 256) {
         const int r = i / d, c = i - r * d;
-        ks[i] = ldf(k + ((long)b * Lk + r) * ldk + h * d + c);
+        ks[r * dp + c] = ldf(k + ((long)b * Lk + r) * ldk + h * d + c);
         vs[i] = ldf(v + ((long)b * Lk + r) * ldv + h * d + c);
     }
-    for (int i = threadIdx.x; i < Lq * d; i += blockDim.x) {
+    for (int i = tid; i < Lq * d; i += 256) {
         const int r = i / d, c = i - r * d;
-        qs[i] = ldf(q + ((long)b * Lq + r) * ldq + h * d + c);
+        qs[r * dp + c] = ldf(q + ((long)b * Lq + r) * ldq + h * d + c);
     }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= Lq) return;
-    const float *qr = qs + t * d;
-    // pass 1: scores and their maximum (kept in LDS-free form: recomputed in pass 2 to stay register-light)
-    float mx = -INFINITY;
-    for (int j = 0; j < Lk; ++j) {
+    for (int i = tid; i < Lq * Lk; i += 256) {
+        const int r = i / Lk, j = i - r * Lk;
         float s = 0.f;
-        for (int c = 0; c < d; ++c) s += qr[c] * ks[j * d + c];
-        s = s * scale + (mask ? mask[(long)b * Lk + j] : 0.f);
-        mx = fmaxf(mx, s);
+        for (int c = 0; c < d; ++c) s += qs[r * dp + c] * ks[j * dp + c];
+        ps[r * lp + j] = s * scale + (mask ? mask[(long)b * Lk + j] : 0.f);
     }
-    float den = 0.f;
-    float acc[128];
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < Lq; r += 4) {
+        float mx = -INFINITY;
+        for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, ps[r * lp + j]);
 #pragma unroll
-    for (int c = 0; c < 128; ++c) acc[c] = 0.f;
-    for (int j = 0; j < Lk; ++j) {
-        float s = 0.f;
-        for (int c = 0; c < d; ++c) s += qr[c] * ks[j * d + c];
-        s = s * scale + (mask ? mask[(long)b * Lk + j] : 0.f);
-        const float p = expf(s - mx);
-        den += p;
-#pragma unroll
-        for (int c = 0; c < 128; ++c)
-            if (c < d) acc[c] += p * vs[j * d + c];
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float den = 0.f;
+        for (int j = lane; j < Lk; j += 64) {
+            const float e = expf(ps[r * lp + j] - mx);
+            ps[r * lp + j] = e;
+            den += e;
+        }
+        den = wave_sum(den);
+        const float inv = 1.0f / den;
+        for (int j = lane; j < Lk; j += 64) ps[r * lp + j] *= inv;
     }
-    const float inv = 1.0f / den;
-    T *orow = out + ((long)b * Lq + t) * ldo + h * d;
-#pragma unroll
-    for (int c = 0; c < 128; ++c)
-        if (c < d) stf(orow + c, acc[c] * inv);
+    __syncthreads();
+    for (int i = tid; i < Lq * d; i += 256) {
+        const int r = i / d, c = i - r * d;
+        float o = 0.f;
+        for (int j = 0; j < Lk; ++j) o += ps[r * lp + j] * vs[j * d + c];
+        stf(out + ((long)b * Lq + r) * ldo + h * d + c, o);
+    }
 }
 
 template <typename T>
@@ -177,10 +180,10 @@ int vk_embed_layernorm(const int64_t *input_ids, const int64_t *token_type_ids, 
 int vk_attention(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const float *mask, void *out, int ldo, int B,
                  int heads, int Lq, int Lk, int d, vk_dtype dt, void *stream) {
     VK_REQUIRE(q && k && v && out, VK_EINVAL, "attention: null argument");
-    VK_REQUIRE(B > 0 && heads > 0 && Lq >= 1 && Lq <= 256 && Lk >= 1 && d >= 1 && d <= 128, VK_EINVAL,
-               "attention: need 1 <= Lq <= 256, d <= 128 (got Lq=%d Lk=%d d=%d)", Lq, Lk, d);
-    const size_t smem = (size_t)(2 * Lk + Lq) * d * sizeof(float);
-    VK_REQUIRE(smem <= 160 * 1024, VK_EINVAL, "attention: (2*Lk+Lq)*d=%d floats do not fit LDS", (2 * Lk + Lq) * d);
+    VK_REQUIRE(B > 0 && heads > 0 && Lq >= 1 && Lk >= 1 && d >= 1, VK_EINVAL, "attention: bad geometry (Lq=%d Lk=%d d=%d)", Lq, Lk, d);
+    const size_t smem = ((size_t)(Lq + Lk) * (d + 1) + (size_t)Lk * d + (size_t)Lq * (Lk + 1)) * sizeof(float);
+    VK_REQUIRE(smem <= 160 * 1024, VK_EINVAL,
+               "attention: one head's Q, K, V and scores (%zu bytes at Lq=%d Lk=%d d=%d) must fit the 160 KiB LDS", smem, Lq, Lk, d);
     const float scale = 1.0f / sqrtf((float)d);
     const dim3 grid(B * heads), block(256);
     hipStream_t s = (hipStream_t)stream;
