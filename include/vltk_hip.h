@@ -227,6 +227,26 @@ int vk_embed_layernorm(const int64_t *input_ids, const int64_t *token_type_ids, 
 int vk_attention(const void *q, int ldq, const void *k, int ldk, const void *v, int ldv, const float *mask,
                  void *out, int ldo, int B, int heads, int Lq, int Lk, int d, vk_dtype dt, void *stream);
 
+/* ---- N4: FPN-side ops (what north_star names; the reference holds only fragments, see oracle/fpn_oracle.py) ---- */
+
+/* RoIAlign over a feature pyramid (torchvision roi_align semantics, `aligned` as detectron2's ROIAlignV2; the level loop of
+ * ROIPooler.forward frcnn.py:1214-1222): maps[l] NHWC [N,Hs[l],Ws[l],C], rois [K,5] (batch,x1,y1,x2,y2), roi_levels [K]
+ * (NULL when levels == 1), out [K,P,P,C].  PARITY UNPINNED (no RoIAlign in the reference). */
+int vk_roi_align(const void *const *maps, const int32_t *Hs, const int32_t *Ws, const float *scales, int levels,
+                 int N, int C, const float *rois, const int32_t *roi_levels, int K, int P, int sampling_ratio,
+                 int aligned, void *out, vk_dtype dt, void *stream);
+/* assign_boxes_to_levels frcnn.py:444-460: floor(canonical_level + log2(sqrt(area)/canonical_box_size + 1e-8)),
+ * clamped to [min_level, max_level], minus min_level.  boxes [K, ld] (x1,y1,x2,y2 first). */
+int vk_assign_levels(const float *boxes, int ld, int K, int min_level, int max_level, float canonical_box_size,
+                     int canonical_level, int32_t *levels_out, void *stream);
+/* FPN top-down step: y = lateral + nearest-2x(top) (detectron2 FPN; absent from the reference: unpinned). NHWC. */
+int vk_upsample2x_add(const void *lateral, const void *top, void *y, int N, int H, int W, int Ht, int Wt, int C,
+                      vk_dtype dt, void *stream);
+/* LastLevelMaxPool frcnn.py:835-836: max_pool2d(kernel 1, stride 2) = every second pixel.  y [N,(H-1)/2+1,(W-1)/2+1,C] */
+int vk_subsample2(const void *x, void *y, int N, int H, int W, int C, vk_dtype dt, void *stream);
+/* the ReLU between LastLevelP6P7's convolutions frcnn.py:852-853 (p6 itself stays un-rectified) */
+int vk_relu_copy(const void *x, void *y, long n, vk_dtype dt, void *stream);
+
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
 int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);
 int vk_nhwc_to_nchw(const void *x, int N, int C, int H, int W, float *y, vk_dtype dt, void *stream);

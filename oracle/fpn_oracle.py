@@ -1,0 +1,79 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the FPN-side pieces.
+
+What the reference holds (frcnn.py): `LastLevelMaxPool` :825-836, `LastLevelP6P7` :839-854, `assign_boxes_to_levels`
+:444-460 (dead code: it calls `.area()` on plain tensors), the multi-level loop of `ROIPooler.forward` :1200-1224 (over
+RoIPool, and unreachable for the same reason).  Those are pinned by vectors from the reference's own classes
+(tools/gen_golden.py --fpn -> tests/golden/fpn_ops.npz).  What it does NOT hold: an FPN neck and RoIAlign, which
+north_star names; they are restated from detectron2's FPN (lateral 1x1 + nearest 2x top-down + 3x3 output convs, all
+with bias, no norm) and torchvision's roi_align -> PARITY UNPINNED for those two.
+Only tests/, smoke() and bench's cpu_baseline may import this module."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .frcnn_oracle import _fp, _lib, roi_pool
+
+
+def last_level_maxpool(p5):                       # frcnn.py:835-836
+    return F.max_pool2d(p5, kernel_size=1, stride=2, padding=0)
+
+
+def last_level_p6p7(c5, w6, b6, w7, b7):           # frcnn.py:850-854
+    p6 = F.conv2d(c5, w6, b6, 2, 1)
+    return p6, F.conv2d(F.relu(p6), w7, b7, 2, 1)
+
+
+def assign_boxes_to_levels(boxes, min_level, max_level, canonical_box_size=224, canonical_level=4):   # frcnn.py:444-460
+    boxes = torch.as_tensor(boxes).float()
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    lv = torch.floor(canonical_level + torch.log2(torch.sqrt(area) / canonical_box_size + 1e-8))
+    return torch.clamp(lv, min=min_level, max=max_level).to(torch.int64) - min_level
+
+
+def roi_align(x, rois, output_size, spatial_scale, sampling_ratio=0, aligned=True):
+    """torchvision.ops.roi_align semantics (oracle/tv_ops.c vko_roi_align).  x [N,C,H,W] f32, rois [K,5]."""
+    x = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
+    r = np.ascontiguousarray(torch.as_tensor(rois).detach().cpu().numpy(), dtype=np.float32)
+    N, C, H, W = x.shape
+    K, P = r.shape[0], int(output_size)
+    out = np.zeros((K, C, P, P), dtype=np.float32)
+    if K:
+        fn = _lib().vko_roi_align
+        fn.restype = None
+        fn(_fp(x), N, C, H, W, _fp(r), K, ctypes.c_float(spatial_scale), P, P, int(sampling_ratio), int(bool(aligned)), _fp(out))
+    return torch.from_numpy(out)
+
+
+def multilevel_pool(feats, scales, rois, output_size, kind="align", sampling_ratio=0, aligned=True, canonical_box_size=224,
+                    canonical_level=4):
+    """ROIPooler.forward :1181-1224 with its level loop (`output[inds] = pooler(x_level, rois[inds])`)."""
+    rois = torch.as_tensor(rois).float()
+    min_level, max_level = int(round(-np.log2(scales[0]))), int(round(-np.log2(scales[-1])))
+    if len(feats) > 1:
+        lv = assign_boxes_to_levels(rois[:, 1:], min_level, max_level, canonical_box_size, canonical_level)
+    else:
+        lv = torch.zeros(len(rois), dtype=torch.int64)
+    out = torch.zeros((len(rois), feats[0].shape[1], output_size, output_size))
+    for li, (x, s) in enumerate(zip(feats, scales)):
+        inds = torch.nonzero(lv == li).squeeze(1)
+        if len(inds) == 0:
+            continue
+        out[inds] = roi_align(x, rois[inds], output_size, s, sampling_ratio, aligned) if kind == "align" else roi_pool(x, rois[inds], output_size, s)
+    return out, lv
+
+
+def fpn_neck(feats, lateral, output, top_block="maxpool"):
+    """detectron2 FPN.forward: feats = [C2..C5] (fine -> coarse); lateral[i] / output[i] = (weight, bias) of the 1x1 / 3x3
+    convs of level i.  Returns [P2, ..., P5, P6]."""
+    prev = F.conv2d(feats[-1], *lateral[-1])
+    results = [F.conv2d(prev, *output[-1], padding=1)]
+    for i in range(len(feats) - 2, -1, -1):
+        top_down = F.interpolate(prev, scale_factor=2.0, mode="nearest")
+        lat = F.conv2d(feats[i], *lateral[i])
+        prev = lat + top_down[:, :, :lat.shape[2], :lat.shape[3]]
+        results.insert(0, F.conv2d(prev, *output[i], padding=1))
+    if top_block == "maxpool":
+        results.append(last_level_maxpool(results[-1]))
+    return results

@@ -68,6 +68,60 @@ void vko_roi_pool(const float *input, int N, int C, int H, int W,
     }
 }
 
+/* RoIAlign forward (torchvision.ops.roi_align CPU kernel semantics, `aligned` as in detectron2's ROIAlignV2).
+ * torchvision is NOT a dependency the reference's FRCNN calls for this (it uses RoIPool): north_star names RoIAlign
+ * (SURVEY.md 8f row N4), no reference vector exists -> parity unpinned; restated from the published kernel:
+ *   offset = aligned ? 0.5 : 0; start = coord*scale - offset; size = end - start (min 1 when !aligned);
+ *   grid = sampling_ratio > 0 ? sampling_ratio : ceil(size / pooled); sample (iy + .5) * bin / grid; bilinear with
+ *   samples beyond [-1, H] x [-1, W] contributing 0 and coordinates clamped to [0, H-1]; mean over the grid.
+ * input NCHW float32, rois [K,5], out [K,C,PH,PW]. */
+static float vko_bilinear(const float *p, int H, int W, float y, float x)
+{
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int yl = (int)y, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * p[yl * W + xl] + w2 * p[yl * W + xh] + w3 * p[yh * W + xl] + w4 * p[yh * W + xh];
+}
+
+void vko_roi_align(const float *input, int N, int C, int H, int W, const float *rois, int K, float spatial_scale,
+                   int PH, int PW, int sampling_ratio, int aligned, float *out)
+{
+    (void)N;
+    for (int k = 0; k < K; ++k) {
+        const float *r = rois + 5 * k;
+        int b = (int)r[0];
+        float off = aligned ? 0.5f : 0.f;
+        float sw = r[1] * spatial_scale - off, sh = r[2] * spatial_scale - off;
+        float ew = r[3] * spatial_scale - off, eh = r[4] * spatial_scale - off;
+        float rw = ew - sw, rh = eh - sh;
+        if (!aligned) { rw = rw > 1.f ? rw : 1.f; rh = rh > 1.f ? rh : 1.f; }
+        float bh = rh / (float)PH, bw = rw / (float)PW;
+        int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+        int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+        float count = (float)(gh * gw > 1 ? gh * gw : 1);
+        for (int c = 0; c < C; ++c) {
+            const float *p = input + ((size_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    float acc = 0.f;
+                    for (int iy = 0; iy < gh; ++iy) {
+                        float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                            acc += vko_bilinear(p, H, W, y, x);
+                        }
+                    }
+                    out[(((size_t)k * C + c) * PH + ph) * PW + pw] = acc / count;
+                }
+        }
+    }
+}
+
 /* stable descending argsort (ties -> lower index first): the build's defined
  * tie order. */
 typedef struct { float s; int64_t i; } vko_si;

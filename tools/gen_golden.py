@@ -343,6 +343,62 @@ def e2e_variants(ref, n=2, h=128, w=160, shapes=((128, 160), (112, 150)), seed=4
     print("e2e_variants.npz:", len(out), "arrays")
 
 
+def fpn_ops(ref):
+    """Vectors for the FPN-side fragments the reference holds: LastLevelMaxPool :825-836,
+    LastLevelP6P7 :839-854, assign_boxes_to_levels :444-460 (called with objects that have `.area()`, which is what
+    the function expects; the reference's own callers pass tensors and never reach it)."""
+    g = torch.Generator().manual_seed(20260202)
+    out = {}
+    x = torch.randn(2, 16, 9, 13, generator=g)
+    out["maxpool/x"], out["maxpool/y"] = np_(x), np_(ref.LastLevelMaxPool()(x)[0])
+    blk = ref.LastLevelP6P7(32, 16).eval()
+    for prm in blk.parameters():
+        prm.data = torch.randn(prm.shape, generator=g) * 0.1
+    c5 = torch.randn(2, 32, 11, 14, generator=g)
+    with torch.no_grad():
+        p6, p7 = blk(c5)
+    out["p6p7/c5"], out["p6p7/p6"], out["p6p7/p7"] = np_(c5), np_(p6), np_(p7)
+    for k, v in blk.state_dict().items():
+        out[f"p6p7/sd/{k}"] = np_(v)
+
+    class B:                                   # what assign_boxes_to_levels expects of a box list
+        def __init__(self, t):
+            self.t = t
+
+        def area(self):
+            return (self.t[:, 2] - self.t[:, 0]) * (self.t[:, 3] - self.t[:, 1])
+    xy = torch.rand(400, 2, generator=g) * 600
+    wh = torch.exp(torch.rand(400, 2, generator=g) * 7.5)            # 1 .. 1800 px sides
+    boxes = torch.cat([xy, xy + wh], 1)
+    exact = torch.tensor([[0, 0, 224, 224], [0, 0, 112, 112], [10, 10, 458, 458], [0, 0, 56, 56], [0, 0, 896, 896], [5, 5, 5, 5],
+                          [0, 0, 1, 1], [0, 0, 4000, 4000]], dtype=torch.float32)
+    boxes = torch.cat([boxes, exact])
+    lv = ref.assign_boxes_to_levels([B(boxes[:200]), B(boxes[200:])], 2, 5, 224, 4)
+    out["levels/boxes"], out["levels/assigned"] = np_(boxes), np_(lv)
+    np.savez_compressed(os.path.join(OUT, "fpn_ops.npz"), **out)
+    print("fpn_ops.npz:", len(out), "arrays; level histogram", np.bincount(out["levels/assigned"]))
+    # multi-level RPN through the reference's RPN class (expected to fail: it stacks per-level anchors of unequal length)
+    try:
+        cfgd = vg_c4_config_dict(depth=50, post_nms_topk=50, detections=8)
+        cfgd["rpn"]["in_features"] = ["p2", "p3"]
+        cfgd["anchor_generator"]["sizes"] = [[32], [64]]
+        cfgd["proposal_generator"]["hidden_channels"] = -1
+        cfg = Config(cfgd)
+        shapes = {"p2": ref.ShapeSpec(channels=16, stride=4), "p3": ref.ShapeSpec(channels=16, stride=8)}
+        rpn = ref.RPN(cfg, shapes).eval()
+        feats = {"p2": torch.randn(1, 16, 12, 16, generator=g), "p3": torch.randn(1, 16, 6, 8, generator=g)}
+        with torch.no_grad():
+            rpn(torch.zeros(1, 3, 48, 64), torch.tensor([[48, 64]]), feats)
+        print("multi-level RPN: the reference ran it")
+    except Exception as e:                                           # recorded in DESIGN.md
+        print("multi-level RPN through the reference's RPN class fails:", type(e).__name__, str(e)[:160])
+
+
+if __name__ == "__main__" and "--fpn" in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    fpn_ops(load_reference())
+    sys.exit(0)
+
 if __name__ == "__main__" and "--variants" in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)

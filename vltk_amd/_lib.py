@@ -93,6 +93,11 @@ SIGNATURES = {
     "vk_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _P]),
     "vk_embed_layernorm": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     "vk_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vk_roi_align": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "vk_assign_levels": (_I, [_P, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "vk_upsample2x_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vk_subsample2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "vk_relu_copy": (_I, [_P, _P, C.c_long, _I, _P]),
     "vk_conv2d": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "vk_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),

@@ -1,0 +1,278 @@
+// N4: the FPN-side kernels north_star names -- RoIAlign over a feature pyramid, level assignment, the
+// neck's top-down nearest-2x upsample + add, the top blocks' stride-2 pick and ReLU copy.  All HBM-bound, NHWC.
+//   roi_align_kernel     torchvision roi_align semantics (`aligned` as detectron2 ROIAlignV2), multi-level: each RoI reads
+//                        the map of its level (assign_boxes_to_levels, frcnn.py:444-460; ROIPooler loop :1214-1222)
+//   assign_levels_kernel floor(canonical_level + log2(sqrt(area)/canonical_size + 1e-8)) clamped, minus min_level
+//   upsample2x_add       y = lateral + nearest2x(top)   (detectron2 FPN top-down path; absent from the reference)
+//   subsample2           LastLevelMaxPool: max_pool2d(k=1, s=2) = every second pixel (frcnn.py:835-836)
+//   relu_copy            the ReLU between LastLevelP6P7's two convs (frcnn.py:852-853)
+#include "vk_common.h"
+
+namespace vk {
+
+constexpr int FPN_MAX_LEVELS = 6;
+
+struct PyramidArgs {
+    const void *map[FPN_MAX_LEVELS];
+    int H[FPN_MAX_LEVELS], W[FPN_MAX_LEVELS];
+    float scale[FPN_MAX_LEVELS];
+    int levels;
+};
+
+template <typename T>
+__device__ __forceinline__ float fld(const T *p) { return (float)*p; }
+
+// one workgroup per (RoI, output bin); lanes over channels.  fp32 arithmetic in the published op order.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(PyramidArgs py, int C, const float *__restrict__ rois,
+                                                       const int32_t *__restrict__ levels, int P, int sampling_ratio, int aligned,
+                                                       T *__restrict__ out) {
+    const int k = blockIdx.x / (P * P), bin = blockIdx.x % (P * P), ph = bin / P, pw = bin % P;
+    const float *r = rois + 5 * (long)k;
+    const int lv = levels ? levels[k] : 0;
+    const T *map = (const T *)py.map[lv];
+    const int H = py.H[lv], W = py.W[lv];
+    const float s = py.scale[lv], off = aligned ? 0.5f : 0.f;
+    const int b = (int)r[0];
+    const float sw = r[1] * s - off, sh = r[2] * s - off, ew = r[3] * s - off, eh = r[4] * s - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!aligned) {
+        rw = fmaxf(rw, 1.f);
+        rh = fmaxf(rh, 1.f);
+    }
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
+    const float count = (float)max(gh * gw, 1);
+    const T *base = map + (long)b * H * W * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                float yy = y;
+                if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+                if (yy <= 0.f) yy = 0.f;
+                if (x <= 0.f) x = 0.f;
+                int yl = (int)yy, xl = (int)x, yh, xh;
+                if (yl >= H - 1) {
+                    yh = yl = H - 1;
+                    yy = (float)yl;
+                } else
+                    yh = yl + 1;
+                if (xl >= W - 1) {
+                    xh = xl = W - 1;
+                    x = (float)xl;
+                } else
+                    xh = xl + 1;
+                const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                acc += w1 * fld(base + ((long)yl * W + xl) * C + c) + w2 * fld(base + ((long)yl * W + xh) * C + c) +
+                       w3 * fld(base + ((long)yh * W + xl) * C + c) + w4 * fld(base + ((long)yh * W + xh) * C + c);
+            }
+        }
+        out[((long)k * P * P + bin) * C + c] = (T)(acc / count);
+    }
+}
+
+// Vector form (C a multiple of 16 B worth of channels): one workgroup per RoI; a group of C/V lanes (V = 16 B of
+// channels per lane) owns one output bin at a time, so every tap of the bilinear stencil is one coalesced row read and
+// every output one coalesced row write.  Same arithmetic and op order as roi_align_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_vec_kernel(PyramidArgs py, int C, const float *__restrict__ rois,
+                                                           const int32_t *__restrict__ levels, int P, int sampling_ratio, int aligned,
+                                                           T *__restrict__ out) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    const int k = blockIdx.x;
+    const float *r = rois + 5 * (long)k;
+    const int lv = levels ? levels[k] : 0;
+    const T *map = (const T *)py.map[lv];
+    const int H = py.H[lv], W = py.W[lv];
+    const float s = py.scale[lv], off = aligned ? 0.5f : 0.f;
+    const int b = (int)r[0];
+    const float sw = r[1] * s - off, sh = r[2] * s - off, ew = r[3] * s - off, eh = r[4] * s - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!aligned) {
+        rw = fmaxf(rw, 1.f);
+        rh = fmaxf(rh, 1.f);
+    }
+    const float bh = rh / (float)P, bw = rw / (float)P;
+    const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)P);
+    const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)P);
+    const float count = (float)max(gh * gw, 1);
+    const T *base = map + (long)b * H * W * C;
+    const int lanes = C / V;                         // lanes per bin (<= 256)
+    const int groups = 256 / lanes, grp = threadIdx.x / lanes, c0 = (threadIdx.x % lanes) * V;
+    if (grp >= groups) return;
+    for (int bin = grp; bin < P * P; bin += groups) {
+        const int ph = bin / P, pw = bin % P;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y0 = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                float yy = y0;
+                if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+                if (yy <= 0.f) yy = 0.f;
+                if (x <= 0.f) x = 0.f;
+                int yl = (int)yy, xl = (int)x, yh, xh;
+                if (yl >= H - 1) {
+                    yh = yl = H - 1;
+                    yy = (float)yl;
+                } else
+                    yh = yl + 1;
+                if (xl >= W - 1) {
+                    xh = xl = W - 1;
+                    x = (float)xl;
+                } else
+                    xh = xl + 1;
+                const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                const vecT v1 = *reinterpret_cast<const vecT *>(base + ((long)yl * W + xl) * C + c0);
+                const vecT v2 = *reinterpret_cast<const vecT *>(base + ((long)yl * W + xh) * C + c0);
+                const vecT v3 = *reinterpret_cast<const vecT *>(base + ((long)yh * W + xl) * C + c0);
+                const vecT v4 = *reinterpret_cast<const vecT *>(base + ((long)yh * W + xh) * C + c0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += w1 * (float)v1[e] + w2 * (float)v2[e] + w3 * (float)v3[e] + w4 * (float)v4[e];
+            }
+        }
+        vecT o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = (T)(acc[e] / count);
+        *reinterpret_cast<vecT *>(out + ((long)k * P * P + bin) * C + c0) = o;
+    }
+}
+
+__global__ void assign_levels_kernel(const float *__restrict__ boxes, int ld, int K, int min_level, int max_level, float canonical_size,
+                                     int canonical_level, int32_t *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float *b = boxes + (long)k * ld;
+    const float area = (b[2] - b[0]) * (b[3] - b[1]);
+    float lv = floorf((float)canonical_level + log2f(sqrtf(area) / canonical_size + 1e-8f));
+    lv = fminf(fmaxf(lv, (float)min_level), (float)max_level);      // NaN (negative area) clamps like torch.clamp: stays NaN -> cast
+    out[k] = (int32_t)lv - min_level;
+}
+
+template <typename T>
+__global__ void upsample2x_add_kernel(const T *__restrict__ lat, const T *__restrict__ top, T *__restrict__ y, int H, int W, int Ht, int Wt,
+                                      int C, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long px = i / C;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const long n = px / ((long)W * H);
+    const int ht = min(h >> 1, Ht - 1), wt = min(w >> 1, Wt - 1);
+    y[i] = (T)((float)lat[i] + (float)top[((n * Ht + ht) * Wt + wt) * C + c]);
+}
+
+template <typename T>
+__global__ void subsample2_kernel(const T *__restrict__ x, T *__restrict__ y, int H, int W, int Ho, int Wo, int C, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long px = i / C;
+    const int wo = (int)(px % Wo), ho = (int)((px / Wo) % Ho);
+    const long n = px / ((long)Wo * Ho);
+    y[i] = x[((n * H + 2 * ho) * W + 2 * wo) * C + c];
+}
+
+template <typename T>
+__global__ void relu_copy_kernel(const T *__restrict__ x, T *__restrict__ y, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const float v = (float)x[i];
+        y[i] = (T)(v > 0.f ? v : 0.f);
+    }
+}
+
+}  // namespace vk
+
+using namespace vk;
+
+#define VK_DT_SWITCH(dt, CALL)                                                          \
+    switch (dt) {                                                                       \
+        case VK_F32: { typedef float T; CALL; } break;                                  \
+        case VK_F16: { typedef _Float16 T; CALL; } break;                               \
+        case VK_BF16: { typedef __bf16 T; CALL; } break;                                \
+        default: VK_REQUIRE(false, VK_EINVAL, "dtype must be f32, f16 or bf16");        \
+    }
+
+extern "C" {
+
+int vk_roi_align(const void *const *maps, const int32_t *Hs, const int32_t *Ws, const float *scales, int levels, int N, int C,
+                 const float *rois, const int32_t *roi_levels, int K, int P, int sampling_ratio, int aligned, void *out, vk_dtype dt,
+                 void *stream) {
+    VK_REQUIRE(maps && Hs && Ws && scales && rois && out, VK_EINVAL, "roi_align: null argument");
+    VK_REQUIRE(levels >= 1 && levels <= FPN_MAX_LEVELS && (levels == 1 || roi_levels), VK_EINVAL, "roi_align: 1..%d levels, level ids needed beyond one",
+               FPN_MAX_LEVELS);
+    VK_REQUIRE(N > 0 && C > 0 && P > 0 && K >= 0 && sampling_ratio >= 0, VK_EINVAL, "roi_align: bad sizes");
+    if (K == 0) return VK_OK;
+    PyramidArgs py;
+    memset(&py, 0, sizeof(py));
+    py.levels = levels;
+    for (int i = 0; i < levels; ++i) {
+        VK_REQUIRE(maps[i] && Hs[i] > 0 && Ws[i] > 0, VK_EINVAL, "roi_align: level %d is empty", i);
+        py.map[i] = maps[i];
+        py.H[i] = Hs[i];
+        py.W[i] = Ws[i];
+        py.scale[i] = scales[i];
+    }
+    const int vec = 16 / (int)dtype_size(dt);
+    if (C % vec == 0 && C / vec <= 256) {            // one workgroup per RoI, 16-byte lanes (the FPN case: C = 256)
+        VK_DT_SWITCH(dt, hipLaunchKernelGGL(roi_align_vec_kernel<T>, dim3(K), dim3(256), 0, (hipStream_t)stream, py, C, rois, roi_levels, P,
+                                            sampling_ratio, aligned, (T *)out));
+    } else {
+        const dim3 grid((unsigned)((long)K * P * P)), block(C >= 256 ? 256 : 64);
+        VK_DT_SWITCH(dt, hipLaunchKernelGGL(roi_align_kernel<T>, grid, block, 0, (hipStream_t)stream, py, C, rois, roi_levels, P, sampling_ratio,
+                                            aligned, (T *)out));
+    }
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+int vk_assign_levels(const float *boxes, int ld, int K, int min_level, int max_level, float canonical_box_size, int canonical_level,
+                     int32_t *levels_out, void *stream) {
+    VK_REQUIRE(boxes && levels_out && ld >= 4 && K >= 0 && min_level <= max_level, VK_EINVAL, "assign_levels: bad arguments");
+    if (K == 0) return VK_OK;
+    hipLaunchKernelGGL(assign_levels_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, ld, K, min_level, max_level,
+                       canonical_box_size, canonical_level, levels_out);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+int vk_upsample2x_add(const void *lateral, const void *top, void *y, int N, int H, int W, int Ht, int Wt, int C, vk_dtype dt, void *stream) {
+    VK_REQUIRE(lateral && top && y && N > 0 && H > 0 && W > 0 && C > 0, VK_EINVAL, "upsample2x_add: bad arguments");
+    VK_REQUIRE(2 * Ht >= H && 2 * Wt >= W, VK_EINVAL, "upsample2x_add: the %dx%d top map does not cover %dx%d", Ht, Wt, H, W);
+    const long total = (long)N * H * W * C;
+    VK_DT_SWITCH(dt, hipLaunchKernelGGL(upsample2x_add_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                        (const T *)lateral, (const T *)top, (T *)y, H, W, Ht, Wt, C, total));
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+int vk_subsample2(const void *x, void *y, int N, int H, int W, int C, vk_dtype dt, void *stream) {
+    VK_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, VK_EINVAL, "subsample2: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)N * Ho * Wo * C;
+    VK_DT_SWITCH(dt, hipLaunchKernelGGL(subsample2_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                        (const T *)x, (T *)y, H, W, Ho, Wo, C, total));
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+int vk_relu_copy(const void *x, void *y, long n, vk_dtype dt, void *stream) {
+    VK_REQUIRE(x && y && n >= 0, VK_EINVAL, "relu_copy: bad arguments");
+    if (n == 0) return VK_OK;
+    VK_DT_SWITCH(dt, hipLaunchKernelGGL(relu_copy_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const T *)x,
+                                        (T *)y, n));
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+}  // extern "C"
