@@ -188,3 +188,25 @@ def test_frcnn_features_into_lxmert_chain(golden_dir):
     ref = LxmertOracle(cfg, sd).forward(ids.numpy(), feats.numpy(), boxes.numpy(), visual_attention_mask=vmask.numpy())
     for a, b in zip(got, ref):
         assert rel(a, b) <= 1e-3
+
+
+def test_graph_replay_matches_eager(g):
+    """One forward captured into a HIP graph (torch.cuda.CUDAGraph over the library's launches) replays bit-identically
+    and follows new inputs of the same shape."""
+    cfg, sd, feats = golden_inputs(g)
+    m = LxmertEncoder(cfg, precision="bf16").load_state_dict(sd)
+    ids, f, p = torch.from_numpy(g["input_ids"]), torch.from_numpy(feats), torch.from_numpy(g["visual_pos"])
+    am, vm = torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["visual_attention_mask"])
+    eager = [t.clone() for t in m(ids, f, p, attention_mask=am, visual_attention_mask=vm)]
+    replay = m.capture(ids, f, p, attention_mask=am, visual_attention_mask=vm)
+    got = replay(ids, f, p, attention_mask=am, visual_attention_mask=vm)
+    torch.cuda.synchronize()
+    for a, b in zip(got, eager):
+        assert torch.equal(a, b)
+    ids2 = torch.roll(ids, 1, dims=1)
+    eager2 = [t.clone() for t in m(ids2, f, p, attention_mask=am, visual_attention_mask=vm)]
+    got2 = replay(ids2, f, p, attention_mask=am, visual_attention_mask=vm)
+    torch.cuda.synchronize()
+    for a, b in zip(got2, eager2):
+        assert torch.equal(a, b)
+    assert not torch.equal(eager2[0], eager[0])

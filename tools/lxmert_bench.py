@@ -42,7 +42,16 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         gf = gflop(cfg, B, 20, 36)
-        print(f"B={B:5d}: {dt * 1e3:8.2f} ms/forward  {B / dt:9.0f} examples/s  {gf / dt / 1e3:7.1f} TFLOP/s (algorithmic {gf:.0f} GFLOP)")
+        replay = m.capture(ids, feats, pos)
+        replay(ids, feats, pos)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            replay(ids, feats, pos)
+        torch.cuda.synchronize()
+        dg = (time.perf_counter() - t0) / n
+        print(f"B={B:5d}: {dt * 1e3:8.2f} ms/forward  {B / dt:9.0f} examples/s  {gf / dt / 1e3:7.1f} TFLOP/s (algorithmic {gf:.0f} GFLOP)"
+              f"   | HIP graph replay: {dg * 1e3:7.2f} ms  {B / dg:9.0f} examples/s")
 
 
 if __name__ == "__main__":

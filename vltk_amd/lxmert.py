@@ -238,8 +238,41 @@ class LxmertEncoder:
         a = self._self_att_block(p + ".attention", x, mask, B, Lx)
         return self._ffn(p + ".intermediate", p + ".output", a)
 
-    @torch.no_grad()
+    def capture(self, input_ids, visual_feats, visual_pos, attention_mask=None, visual_attention_mask=None, token_type_ids=None):
+        """Capture one forward for these input SHAPES into a HIP graph (~430 launches become one graph launch: the
+        small-batch forward is launch-bound).  Returns `replay(input_ids, visual_feats, visual_pos, ...)`, which copies the
+        new inputs into the captured buffers, launches the graph and returns the (static) output tensors."""
+        dev = self.device
+        static = dict(ids=input_ids.to(dev).clone(), vf=visual_feats.to(dev).clone(), vp=visual_pos.to(dev).clone(),
+                      am=None if attention_mask is None else attention_mask.to(dev).clone(),
+                      vm=None if visual_attention_mask is None else visual_attention_mask.to(dev).clone(),
+                      tt=None if token_type_ids is None else token_type_ids.to(dev).clone())
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                    # warm-up: one-time attribute / lazy-init calls must not be captured
+            self._forward(static["ids"], static["vf"], static["vp"], static["am"], static["vm"], static["tt"])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self._forward(static["ids"], static["vf"], static["vp"], static["am"], static["vm"], static["tt"])
+
+        def replay(input_ids, visual_feats, visual_pos, attention_mask=None, visual_attention_mask=None, token_type_ids=None):
+            for key, val in (("ids", input_ids), ("vf", visual_feats), ("vp", visual_pos), ("am", attention_mask),
+                             ("vm", visual_attention_mask), ("tt", token_type_ids)):
+                if static[key] is not None:
+                    static[key].copy_(val)
+            graph.replay()
+            return outs
+        return replay
+
     def __call__(self, input_ids, visual_feats, visual_pos, attention_mask=None, visual_attention_mask=None, token_type_ids=None):
+        out = self._forward(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids)
+        torch.cuda.synchronize(self.device)
+        return out
+
+    @torch.no_grad()
+    def _forward(self, input_ids, visual_feats, visual_pos, attention_mask=None, visual_attention_mask=None, token_type_ids=None):
         if not self._loaded:
             raise RuntimeError("LxmertEncoder: load_state_dict() first")
         cfg, dev = self.cfg, self.device
@@ -252,7 +285,7 @@ class LxmertEncoder:
 
         def ext(m):                                     # LxmertModel.forward :766-784
             return None if m is None else ((1.0 - m.to(dev, torch.float32)) * fmin).contiguous()
-        lmask = ext(torch.ones((B, Lq)) if attention_mask is None else attention_mask)
+        lmask = ext(torch.ones((B, Lq), device=dev) if attention_mask is None else attention_mask)
         vmask = ext(visual_attention_mask)
         # embeddings :191-214
         lang = torch.empty((B * Lq, H), dtype=self.tdt, device=dev)
@@ -284,5 +317,4 @@ class LxmertEncoder:
         pooled = torch.empty((B, H), dtype=self.tdt, device=dev)
         L.call("vk_conv2d", lang.data_ptr(), B, Lq, 1, H, w.data_ptr(), bb.data_ptr(), None, pooled.data_ptr(), H, H, 1, 1, Lq, 0, 1, 1,
                L.VK_ACT_TANH, self.dt, self.dt, self._stream())
-        torch.cuda.synchronize(dev)
         return lang.view(B, Lq, H), visn.view(B, V, H), pooled
