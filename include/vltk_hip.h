@@ -247,6 +247,20 @@ int vk_subsample2(const void *x, void *y, int N, int H, int W, int C, vk_dtype d
 /* the ReLU between LastLevelP6P7's convolutions frcnn.py:852-853 (p6 itself stays un-rectified) */
 int vk_relu_copy(const void *x, void *y, long n, vk_dtype dt, void *stream);
 
+/* find_top_rpn_proposals frcnn.py:264-390 over SEVERAL levels (the reference's RPN class itself cannot run them: its
+ * AnchorGenerator stacks per-level anchors of unequal length; the function and the per-level pieces can, which is how the
+ * golden vectors are made): per level top pre_nms_topk of [N,Hl,Wl,A] logits (row stride ld), decode with that level's cell
+ * anchors / stride, clip, size filter; concat level-major; batched NMS (torchvision form: boxes shifted by
+ * level * (max coordinate + 1)); first post_nms_topk.  levels * pre_nms_topk <= 8192.  Outputs as vk_rpn_proposals. */
+size_t vk_rpn_multilevel_workspace_bytes(int N, int levels, int pre_topk, int post_topk);
+int vk_rpn_proposals_multilevel(const float *const *logits, const int32_t *ld_logits, const float *const *deltas,
+                                const int32_t *ld_deltas, int levels, int N, const int32_t *Hs, const int32_t *Ws, int A,
+                                const float *const *cell_anchors, const int32_t *strides, float offset,
+                                const int32_t *image_hw, const float *bbox_weights4_host, float min_size,
+                                double nms_thresh, int pre_topk, int post_topk, float *out_boxes, float *out_logits,
+                                int32_t *out_counts, int32_t *nonfinite_flag, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
 /* NCHW f32 -> NHWC (dt) and back (layout plumbing for tests). */
 int vk_nchw_to_nhwc(const float *x, int N, int C, int H, int W, void *y, vk_dtype dt, void *stream);
 int vk_nhwc_to_nchw(const void *x, int N, int C, int H, int W, float *y, vk_dtype dt, void *stream);

@@ -77,3 +77,43 @@ def fpn_neck(feats, lateral, output, top_block="maxpool"):
     if top_block == "maxpool":
         results.append(last_level_maxpool(results[-1]))
     return results
+
+
+def multilevel_proposals(objs, deltas, cell_anchors, strides, image_shapes, pre_topk, post_topk, nms_thresh, min_size=0.0,
+                         weights=(1.0, 1.0, 1.0, 1.0), offset=0.0):
+    """find_top_rpn_proposals frcnn.py:264-390 over several levels (per-level top-k, concat, clip, size filter, batched NMS
+    with level ids, first post_topk), fed by per-level RPNOutputs decoding (:758-780).  objs[l] [N,A,Hl,Wl], deltas[l]
+    [N,4A,Hl,Wl], cell_anchors[l] [A,4].  Returns per image (boxes [<=R,4], logits [<=R])."""
+    from .frcnn_oracle import FRCNNOracle, argsort_desc, batched_nms
+    N = objs[0].shape[0]
+    tk_boxes, tk_scores, lvl_ids = [], [], []
+    for li, (obj, dlt, base, stride) in enumerate(zip(objs, deltas, cell_anchors, strides)):
+        _, A, Hf, Wf = obj.shape
+        sx = torch.arange(offset * stride, Wf * stride, step=stride, dtype=torch.float32)
+        sy = torch.arange(offset * stride, Hf * stride, step=stride, dtype=torch.float32)
+        yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+        shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+        anchors = (shifts.view(-1, 1, 4) + torch.as_tensor(base).float().view(1, -1, 4)).reshape(-1, 4)
+        d = dlt.view(N, A, 4, Hf, Wf).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+        props = FRCNNOracle.apply_deltas(d, anchors.unsqueeze(0).expand(N, -1, -1).reshape(-1, 4), weights).view(N, -1, 4)
+        logits = obj.permute(0, 2, 3, 1).reshape(N, -1)
+        k = min(pre_topk, logits.shape[1])
+        b_l, s_l = [], []
+        for n in range(N):
+            order = argsort_desc(logits[n])[:k]
+            b_l.append(props[n][order])
+            s_l.append(logits[n][order])
+        tk_boxes.append(torch.stack(b_l))
+        tk_scores.append(torch.stack(s_l))
+        lvl_ids.append(torch.full((k,), li, dtype=torch.int64))
+    boxes_all, scores_all, lvl_all = torch.cat(tk_boxes, 1), torch.cat(tk_scores, 1), torch.cat(lvl_ids)
+    res = []
+    for n in range(N):
+        boxes, scores, lvl = boxes_all[n].clone(), scores_all[n], lvl_all
+        FRCNNOracle.clip_box(boxes, image_shapes[n])
+        keep = ((boxes[:, 2] - boxes[:, 0]) > min_size) & ((boxes[:, 3] - boxes[:, 1]) > min_size)
+        if int(keep.sum()) != len(boxes):
+            boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+        k = batched_nms(boxes, scores, lvl, nms_thresh)[:post_topk]
+        res.append((boxes[k], scores[k]))
+    return res

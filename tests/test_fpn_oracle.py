@@ -51,3 +51,22 @@ def test_multilevel_pool_routes_by_level():
     for k in range(4):
         li = int(lv[k])
         np.testing.assert_array_equal(out[k].numpy(), fo.roi_align(feats[li], rois[k:k + 1], 7, scales[li], 2, True)[0].numpy())
+
+
+def _ml_inputs(g):
+    L_ = 3
+    objs = [torch.from_numpy(g[f"mlrpn/obj_{i}"]) for i in range(L_)]
+    dlts = [torch.from_numpy(g[f"mlrpn/dlt_{i}"]) for i in range(L_)]
+    cells = [g[f"mlrpn/cell_{i}"] for i in range(L_)]
+    pre, post, thr = g["mlrpn/pre_post_thr"].tolist()
+    return objs, dlts, cells, g["mlrpn/strides"].tolist(), g["mlrpn/shapes"].tolist(), int(pre), int(post), float(thr)
+
+
+def test_multilevel_proposals_vs_reference(g):
+    """find_top_rpn_proposals over three levels, run by the reference itself on per-level inputs decoded with its own
+    AnchorGenerator / Box2BoxTransform."""
+    objs, dlts, cells, strides, shapes, pre, post, thr = _ml_inputs(g)
+    res = fo.multilevel_proposals(objs, dlts, cells, strides, shapes, pre, post, thr)
+    for i, (b, s_) in enumerate(res):
+        np.testing.assert_array_equal(s_.numpy(), g[f"mlrpn/logits_{i}"])
+        np.testing.assert_allclose(b.numpy(), g[f"mlrpn/boxes_{i}"], rtol=0, atol=1e-4)

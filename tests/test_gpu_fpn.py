@@ -116,3 +116,65 @@ def test_fpn_neck_vs_oracle(precision, td, tol):
     for a, b in zip(got, ref):
         assert tuple(nchw(a).shape) == tuple(b.shape)
         assert G.rel_err(nchw(a), b) <= tol
+
+
+def _ml_call(objs, dlts, cells, strides, shapes, pre, post, thr, min_size=0.0):
+    import ctypes as C
+    nl, N, A = len(objs), objs[0].shape[0], objs[0].shape[1]
+    lg = [o.permute(0, 2, 3, 1).contiguous().to(G.DEV) for o in objs]                      # [N,H,W,A]
+    dl = [d.view(N, A, 4, d.shape[2], d.shape[3]).permute(0, 3, 4, 1, 2).reshape(N, d.shape[2], d.shape[3], 4 * A).contiguous().to(G.DEV)
+          for d in dlts]                                                                   # [N,H,W,4A] in (a, coord) order
+    ce = [torch.from_numpy(np.ascontiguousarray(c, np.float32)).to(G.DEV) for c in cells]
+    P_ = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    I_ = lambda vs: (C.c_int32 * nl)(*[int(v) for v in vs])
+    hw = torch.tensor(shapes, dtype=torch.int32, device=G.DEV)
+    wts = (C.c_float * 4)(1.0, 1.0, 1.0, 1.0)
+    ob = torch.zeros((N, post, 4), device=G.DEV)
+    ol = torch.zeros((N, post), device=G.DEV)
+    oc = torch.zeros(N, dtype=torch.int32, device=G.DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=G.DEV)
+    nb = L.load().vk_rpn_multilevel_workspace_bytes(N, nl, pre, post)
+    ws = torch.empty(nb, dtype=torch.uint8, device=G.DEV)
+    L.call("vk_rpn_proposals_multilevel", P_(lg), I_([A] * nl), P_(dl), I_([4 * A] * nl), nl, N, I_([o.shape[2] for o in objs]),
+           I_([o.shape[3] for o in objs]), A, P_(ce), I_(strides), 0.0, G.P(hw), wts, min_size, thr, pre, post, G.P(ob), G.P(ol), G.P(oc),
+           G.P(flag), G.P(ws), nb, G.stream())
+    torch.cuda.synchronize()
+    assert int(flag) == 0
+    return ob.cpu(), ol.cpu(), oc.cpu()
+
+
+def test_multilevel_proposals_vs_reference(g):
+    from test_fpn_oracle import _ml_inputs
+    objs, dlts, cells, strides, shapes, pre, post, thr = _ml_inputs(g)
+    ob, ol, oc = _ml_call(objs, dlts, cells, strides, shapes, pre, post, thr)
+    for i in range(len(shapes)):
+        c = int(oc[i])
+        assert c == len(g[f"mlrpn/logits_{i}"])
+        np.testing.assert_array_equal(ol[i, :c].numpy(), g[f"mlrpn/logits_{i}"])
+        assert G.rel_err(ob[i, :c], g[f"mlrpn/boxes_{i}"]) <= 2e-6
+
+
+def test_multilevel_proposals_fpn_size_vs_oracle():
+    """Five levels of an 800x1333 image (strides 4..64, 3 anchors per cell, 1000 per level -> 1000 kept)."""
+    gen = np.random.Generator(np.random.PCG64(4))
+    strides = [4, 8, 16, 32, 64]
+    hw = [(200, 334), (100, 167), (50, 84), (25, 42), (13, 21)]
+    A, N = 3, 2
+    objs = [torch.from_numpy(gen.standard_normal((N, A, h, w)).astype(np.float32)) for h, w in hw]
+    dlts = [torch.from_numpy((gen.standard_normal((N, 4 * A, h, w)) * 0.5).astype(np.float32)) for h, w in hw]
+    cells = []
+    for sz in (32, 64, 128, 256, 512):
+        c = []
+        for r in (0.5, 1.0, 2.0):
+            w_ = (sz * sz / r) ** 0.5
+            h_ = r * w_
+            c.append([-w_ / 2, -h_ / 2, w_ / 2, h_ / 2])
+        cells.append(np.asarray(c, np.float32))
+    shapes = [[800, 1333], [760, 1200]]
+    ob, ol, oc = _ml_call(objs, dlts, cells, strides, shapes, 1000, 1000, 0.7)
+    ref = fo.multilevel_proposals(objs, dlts, cells, strides, shapes, 1000, 1000, 0.7)
+    for i, (b, s_) in enumerate(ref):
+        c = int(oc[i])
+        assert c == len(s_)
+        np.testing.assert_array_equal(ol[i, :c].numpy(), s_.numpy())
+        assert G.rel_err(ob[i, :c], b) <= 2e-6

@@ -375,6 +375,36 @@ def fpn_ops(ref):
     boxes = torch.cat([boxes, exact])
     lv = ref.assign_boxes_to_levels([B(boxes[:200]), B(boxes[200:])], 2, 5, 224, 4)
     out["levels/boxes"], out["levels/assigned"] = np_(boxes), np_(lv)
+    # multi-level proposals: the reference's RPN class cannot run several levels (below), but its pieces can: per-level
+    # anchors from AnchorGenerator.grid_anchors, per-level decoding with Box2BoxTransform.apply_deltas in RPNOutputs' (n, y, x, a)
+    # order (:758-780), then find_top_rpn_proposals itself over the list of levels (:264-390)
+    cfgd = vg_c4_config_dict(depth=50, post_nms_topk=40, detections=8)
+    cfgd["anchor_generator"]["sizes"] = [[32], [64], [128]]
+    cfg = Config(cfgd)
+    strides, A, N = [4, 8, 16], 3, 2
+    shapes_in = [ref.ShapeSpec(channels=8, stride=st) for st in strides]
+    ag = ref.AnchorGenerator(cfg, shapes_in)
+    hw = [(24, 32), (12, 16), (6, 8)]
+    tr = ref.Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0))
+    img_shapes = [(96, 128), (90, 117)]
+    props, logits = [], []
+    for li, (h, w) in enumerate(hw):
+        obj = torch.randn(N, A, h, w, generator=g)
+        tie_free(np_(obj), f"rpn level {li} logits")
+        dlt = torch.randn(N, 4 * A, h, w, generator=g) * 0.4
+        anchors = ag.grid_anchors(hw)[li]
+        d = dlt.view(N, A, 4, h, w).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+        anc = anchors.unsqueeze(0).expand(N, -1, -1).reshape(-1, 4)
+        props.append(tr.apply_deltas(d, anc).view(N, -1, 4))
+        logits.append(obj.permute(0, 2, 3, 1).reshape(N, -1))
+        out[f"mlrpn/obj_{li}"], out[f"mlrpn/dlt_{li}"] = np_(obj), np_(dlt)
+        out[f"mlrpn/cell_{li}"] = np_(ag.cell_anchors[li])
+    res = ref.find_top_rpn_proposals(props, logits, [None] * N, img_shapes, 0.7, 200, 40, 0, False)
+    for i, (b, sc) in enumerate(res):
+        out[f"mlrpn/boxes_{i}"], out[f"mlrpn/logits_{i}"] = np_(b), np_(sc)
+    out["mlrpn/strides"], out["mlrpn/shapes"] = np.asarray(strides), np.asarray(img_shapes)
+    out["mlrpn/pre_post_thr"] = np.asarray([200, 40, 0.7])
+    print("multi-level proposals kept:", [len(b) for b, _ in res])
     np.savez_compressed(os.path.join(OUT, "fpn_ops.npz"), **out)
     print("fpn_ops.npz:", len(out), "arrays; level histogram", np.bincount(out["levels/assigned"]))
     # multi-level RPN through the reference's RPN class (expected to fail: it stacks per-level anchors of unequal length)

@@ -98,6 +98,8 @@ SIGNATURES = {
     "vk_upsample2x_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_subsample2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "vk_relu_copy": (_I, [_P, _P, C.c_long, _I, _P]),
+    "vk_rpn_multilevel_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "vk_rpn_proposals_multilevel": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _F, _P, _P, _F, _D, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
     "vk_conv2d": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vk_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "vk_nhwc_to_nchw": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),

@@ -455,6 +455,86 @@ static int next_pow2(int v) {
     return p;
 }
 
+// ---------------------------------------------------------------------------
+// Several levels (find_top_rpn_proposals frcnn.py:264-390 with a list of levels; N4): the per-level candidates (each
+// level's top-k, decoded / clipped / size-flagged by rpn_select_decode_kernel) are merged per image in the concat order
+// (level-major, rank-minor), the size-filtered ones dropped, and sorted by logit (ties -> lower concat index).  NMS
+// runs on boxes shifted by level * (max coordinate + 1) exactly like torchvision's batched_nms (frcnn.py:383), so boxes
+// of different levels never overlap; the un-shifted boxes are what comes out.
+constexpr int RPN_MAX_LEVELS = 6;
+struct LevelCands {
+    const float *boxes[RPN_MAX_LEVELS];
+    const float *logit[RPN_MAX_LEVELS];
+    const int32_t *valid[RPN_MAX_LEVELS];
+    const int32_t *count[RPN_MAX_LEVELS];
+    int levels, pre;
+};
+
+__global__ __launch_bounds__(RPN_THREADS) void rpn_merge_levels_kernel(LevelCands lc, int cap, int sortn, float *__restrict__ m_boxes,
+                                                                       float *__restrict__ m_shift, float *__restrict__ m_logit,
+                                                                       int32_t *__restrict__ m_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(smem_raw);   // [sortn]
+    float *red = reinterpret_cast<float *>(skey + sortn);                          // [RPN_THREADS / 64]
+    __shared__ int sh_cnt;
+    const int n = blockIdx.x, tid = threadIdx.x, pre = lc.pre;
+    if (tid == 0) sh_cnt = 0;
+    __syncthreads();
+    float mx = -INFINITY;
+    int local = 0;
+    for (int i = tid; i < sortn; i += RPN_THREADS) {
+        unsigned long long key = ~0ull;
+        if (i < lc.levels * pre) {
+            const int l = i / pre, r = i - l * pre;
+            if (r < lc.count[l][n] && lc.valid[l][(long)n * pre + r]) {
+                key = ((unsigned long long)desc_key(lc.logit[l][(long)n * pre + r]) << 32) | (uint32_t)i;
+                const float *b = lc.boxes[l] + ((long)n * pre + r) * 4;
+                mx = fmaxf(mx, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+                ++local;
+            }
+        }
+        skey[i] = key;
+    }
+    atomicAdd(&sh_cnt, local);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < RPN_THREADS / 64; ++w) mx = fmaxf(mx, red[w]);
+    const int cnt = sh_cnt;
+    for (int k2 = 2; k2 <= sortn; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int i = tid; i < sortn; i += RPN_THREADS) {
+                int ixj = i ^ j2;
+                if (ixj > i) {
+                    unsigned long long a = skey[i], b = skey[ixj];
+                    bool up = (i & k2) == 0;
+                    if ((a > b) == up) {
+                        skey[i] = b;
+                        skey[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const float step = mx + 1.0f;                       // offsets = idxs.to(boxes) * (max_coordinate + 1)
+    for (int e = tid; e < cnt; e += RPN_THREADS) {
+        const uint32_t slot = (uint32_t)(skey[e] & 0xFFFFFFFFull);
+        const int l = slot / pre, r = slot - l * pre;
+        const float *b = lc.boxes[l] + ((long)n * pre + r) * 4;
+        const float off = (float)l * step;
+        float *ob = m_boxes + ((long)n * cap + e) * 4, *os = m_shift + ((long)n * cap + e) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ob[c] = b[c];
+            os[c] = b[c] + off;
+        }
+        m_logit[(long)n * cap + e] = lc.logit[l][(long)n * pre + r];
+    }
+    if (tid == 0) m_count[n] = cnt;
+}
+
 struct RpnWs {
     float *cand_boxes;
     float *cand_logit;
@@ -544,6 +624,110 @@ int vk_rpn_proposals(const float *logits, int ld_logits, const float *deltas, in
     VK_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rpn_gather_kernel, dim3(N), dim3(256), 0, s, w.cand_boxes, w.cand_logit, pre_topk, w.keep_idx,
                        w.keep_count, post_topk, out_boxes, out_logits, out_counts);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
+}
+
+struct MlWs {
+    RpnWs lv[RPN_MAX_LEVELS];
+    float *m_boxes, *m_shift, *m_logit;
+    int32_t *m_count;
+    unsigned long long *mask;
+    int32_t *keep_idx, *keep_count;
+    size_t total;
+};
+
+static MlWs carve_ml_ws(void *base, int N, int levels, int pre, int post) {
+    MlWs w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *r = p ? p + off : nullptr;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    for (int l = 0; l < levels; ++l) {
+        w.lv[l].cand_boxes = (float *)take((size_t)N * pre * 4 * sizeof(float));
+        w.lv[l].cand_logit = (float *)take((size_t)N * pre * sizeof(float));
+        w.lv[l].cand_valid = (int32_t *)take((size_t)N * pre * sizeof(int32_t));
+        w.lv[l].cand_count = (int32_t *)take((size_t)N * sizeof(int32_t));
+    }
+    const int cap = levels * pre, nwords = ceil_div(cap, 64);
+    w.m_boxes = (float *)take((size_t)N * cap * 4 * sizeof(float));
+    w.m_shift = (float *)take((size_t)N * cap * 4 * sizeof(float));
+    w.m_logit = (float *)take((size_t)N * cap * sizeof(float));
+    w.m_count = (int32_t *)take((size_t)N * sizeof(int32_t));
+    w.mask = (unsigned long long *)take((size_t)N * cap * nwords * 8);
+    w.keep_idx = (int32_t *)take((size_t)N * post * sizeof(int32_t));
+    w.keep_count = (int32_t *)take((size_t)N * sizeof(int32_t));
+    w.total = off;
+    return w;
+}
+
+size_t vk_rpn_multilevel_workspace_bytes(int N, int levels, int pre_topk, int post_topk) {
+    if (levels < 1 || levels > RPN_MAX_LEVELS) return 0;
+    return carve_ml_ws(nullptr, N, levels, pre_topk, post_topk).total;
+}
+
+int vk_rpn_proposals_multilevel(const float *const *logits, const int32_t *ld_logits, const float *const *deltas, const int32_t *ld_deltas,
+                                int levels, int N, const int32_t *Hs, const int32_t *Ws, int A, const float *const *cell_anchors,
+                                const int32_t *strides, float offset, const int32_t *image_hw, const float *bbox_weights4_host,
+                                float min_size, double nms_thresh, int pre_topk, int post_topk, float *out_boxes, float *out_logits,
+                                int32_t *out_counts, int32_t *nonfinite_flag, void *workspace, size_t workspace_bytes, void *stream) {
+    VK_REQUIRE(logits && deltas && Hs && Ws && cell_anchors && strides && image_hw && bbox_weights4_host, VK_EINVAL, "rpn_ml: null argument");
+    VK_REQUIRE(levels >= 1 && levels <= RPN_MAX_LEVELS && N > 0 && A > 0, VK_EINVAL, "rpn_ml: 1..%d levels", RPN_MAX_LEVELS);
+    VK_REQUIRE(pre_topk > 0 && (long)levels * pre_topk <= RPN_MAX_PRE, VK_EINVAL,
+               "rpn_ml: levels * pre_nms_topk = %ld must be in 1..%d", (long)levels * pre_topk, RPN_MAX_PRE);
+    VK_REQUIRE(post_topk > 0 && post_topk <= levels * pre_topk, VK_EINVAL, "rpn_ml: post_nms_topk=%d out of range", post_topk);
+    MlWs w = carve_ml_ws(workspace, N, levels, pre_topk, post_topk);
+    VK_REQUIRE(workspace && workspace_bytes >= w.total, VK_EINVAL, "rpn_ml: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rpn_select_decode_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RPN_MAX_PRE * 8 + 2048));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rpn_merge_levels_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RPN_MAX_PRE * 8 + 256));
+        attr_set = true;
+    }
+    LevelCands lc;
+    memset(&lc, 0, sizeof(lc));
+    lc.levels = levels;
+    lc.pre = pre_topk;
+    for (int l = 0; l < levels; ++l) {
+        const long HWA = (long)Hs[l] * Ws[l] * A;
+        VK_REQUIRE(Hs[l] > 0 && Ws[l] > 0 && HWA < (1L << 31), VK_EINVAL, "rpn_ml: level %d has a bad size", l);
+        const int K = (int)(pre_topk < HWA ? pre_topk : HWA);
+        const int sortn = next_pow2(K);
+        DecodeCfg cfg;
+        cfg.wx = bbox_weights4_host[0];
+        cfg.wy = bbox_weights4_host[1];
+        cfg.ww = bbox_weights4_host[2];
+        cfg.wh = bbox_weights4_host[3];
+        cfg.scale_clamp = (float)log(1000.0 / 16.0);
+        cfg.min_size = min_size;
+        cfg.stride = strides[l];
+        cfg.offset = offset;
+        hipLaunchKernelGGL(rpn_select_decode_kernel, dim3(N), dim3(RPN_THREADS), (size_t)sortn * 8 + 2048, s, logits[l], ld_logits[l], deltas[l],
+                           ld_deltas[l], Hs[l], Ws[l], A, cell_anchors[l], image_hw, cfg, pre_topk, sortn, w.lv[l].cand_boxes,
+                           w.lv[l].cand_logit, w.lv[l].cand_valid, w.lv[l].cand_count, nonfinite_flag);
+        VK_CHECK_HIP(hipGetLastError());
+        lc.boxes[l] = w.lv[l].cand_boxes;
+        lc.logit[l] = w.lv[l].cand_logit;
+        lc.valid[l] = w.lv[l].cand_valid;
+        lc.count[l] = w.lv[l].cand_count;
+    }
+    const int cap = levels * pre_topk, sortn = next_pow2(cap), nwords = ceil_div(cap, 64);
+    hipLaunchKernelGGL(rpn_merge_levels_kernel, dim3(N), dim3(RPN_THREADS), (size_t)sortn * 8 + 256, s, lc, cap, sortn, w.m_boxes, w.m_shift,
+                       w.m_logit, w.m_count);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, N), dim3(64), 0, s, w.m_shift, w.m_count, cap, nwords, nms_thresh, w.mask);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, w.mask, (const int32_t *)nullptr, w.m_count, cap, nwords, post_topk,
+                       w.keep_idx, w.keep_count);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rpn_gather_kernel, dim3(N), dim3(256), 0, s, w.m_boxes, w.m_logit, cap, w.keep_idx, w.keep_count, post_topk, out_boxes,
+                       out_logits, out_counts);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
