@@ -110,3 +110,17 @@ class LxmertOracle:
         pooled = self.linear(lang[:, 0], "pooler.dense", act="tanh")
         out = (lang, visn, pooled)
         return (out, st) if return_stages else out
+
+
+    def qa_forward(self, *args, **kw):
+        """LxmertForQuestionAnswering.forward :1255-1270 (state dict with the `lxmert.` prefix and `answer_head.logit_fc.*`):
+        answer_head(pooled) = Linear -> GELU -> LayerNorm -> Linear (:602-614)."""
+        full = self.sd
+        self.sd = {k[len("lxmert."):]: v for k, v in full.items() if k.startswith("lxmert.")}
+        try:
+            _, _, pooled = self.forward(*args, **kw)
+        finally:
+            self.sd = full
+        h = self.linear(pooled, "answer_head.logit_fc.0", act="gelu")
+        h = self.q(self.ln(h, "answer_head.logit_fc.2"))
+        return self.linear(h, "answer_head.logit_fc.3")

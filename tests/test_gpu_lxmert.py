@@ -210,3 +210,22 @@ def test_graph_replay_matches_eager(g):
     for a, b in zip(got2, eager2):
         assert torch.equal(a, b)
     assert not torch.equal(eager2[0], eager[0])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+def test_question_answering_head(g, precision, tol):
+    """BASELINE config 5's model: LxmertForQuestionAnswering on the HIP path vs transformers' vectors (fp32) / the
+    bf16-emulating oracle; the arg-max answers agree with transformers'."""
+    from vltk_amd.lxmert import LxmertForQuestionAnswering, make_lxmert_qa_state_dict
+    cfg, _, feats = golden_inputs(g)
+    nqa = int(g["qa/num_labels"])
+    sd = make_lxmert_qa_state_dict(cfg, nqa, int(g["seed"]))
+    m = LxmertForQuestionAnswering(cfg, nqa, precision=precision).load_state_dict(sd)
+    kw = case_kwargs(g, "masked")
+    score = m(torch.from_numpy(g["input_ids"]), torch.from_numpy(feats), torch.from_numpy(g["visual_pos"]),
+              **{k: torch.from_numpy(v) for k, v in kw.items()})
+    ref = g["qa/question_answering_score"] if precision == "fp32" else \
+        LxmertOracle(cfg, sd, emulate=precision).qa_forward(g["input_ids"], feats, g["visual_pos"], **kw)
+    assert score.shape == (3, nqa)
+    assert rel(score, ref) <= tol
+    assert score.float().argmax(-1).cpu().tolist() == g["qa/question_answering_score"].argmax(-1).tolist()

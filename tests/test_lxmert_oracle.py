@@ -49,3 +49,12 @@ def test_param_spec_matches_transformers():
         with torch.device("meta"):
             m = tr.LxmertModel(tr.LxmertConfig(**cfg))
         assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in lxmert_param_spec(cfg)]
+
+
+def test_qa_oracle_vs_transformers_golden(g):
+    """LxmertForQuestionAnswering (encoder + answer head) vs the vectors transformers produced."""
+    from vltk_amd.lxmert import make_lxmert_qa_state_dict
+    cfg, _, feats = golden_inputs(g)
+    sd = make_lxmert_qa_state_dict(cfg, int(g["qa/num_labels"]), int(g["seed"]))
+    score = LxmertOracle(cfg, sd).qa_forward(g["input_ids"], feats, g["visual_pos"], **case_kwargs(g, "masked"))
+    assert rel(score, g["qa/question_answering_score"]) <= 1e-5

@@ -58,6 +58,19 @@ def main():
             print(tag, "lang |max| %.3f visn |max| %.3f pooled |max| %.3f" % (np.abs(out[f"{tag}/language_output"]).max(),
                                                                              np.abs(out[f"{tag}/vision_output"]).max(),
                                                                              np.abs(out[f"{tag}/pooled_output"]).max()))
+    # LxmertForQuestionAnswering (the VQA / GQA model the reference's training script instantiates): encoder + answer head
+    from transformers import LxmertForQuestionAnswering
+    from vltk_amd.lxmert import lxmert_qa_param_spec, make_lxmert_qa_state_dict
+    NQA = 40
+    qa = LxmertForQuestionAnswering(LxmertConfig(num_qa_labels=NQA, **cfg)).eval()
+    assert [(k, tuple(v.shape)) for k, v in qa.state_dict().items()] == [(k, tuple(s_)) for k, s_ in lxmert_qa_param_spec(cfg, NQA)]
+    qa.load_state_dict({k: torch.from_numpy(v) for k, v in make_lxmert_qa_state_dict(cfg, NQA, seed).items()}, strict=True)
+    with torch.no_grad():
+        o = qa(input_ids=torch.from_numpy(ids), visual_feats=torch.from_numpy(feats), visual_pos=torch.from_numpy(pos),
+               attention_mask=torch.from_numpy(amask), visual_attention_mask=torch.from_numpy(vmask), token_type_ids=torch.from_numpy(tts))
+    out["qa/num_labels"] = np.asarray(NQA)
+    out["qa/question_answering_score"] = o.question_answering_score.numpy()
+    print("qa score |max| %.3f argmax %s" % (np.abs(out["qa/question_answering_score"]).max(), out["qa/question_answering_score"].argmax(-1)))
     # the visual features are regenerated from the seed by the tests (3 x 36 x 2048 floats would dominate the file)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lxmert_small.npz"), **out)
     print("lxmert_small.npz:", len(out), "arrays")

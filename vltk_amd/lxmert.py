@@ -69,6 +69,23 @@ def lxmert_param_spec(cfg):
     return spec
 
 
+def lxmert_qa_param_spec(cfg, num_qa_labels):
+    """`transformers.LxmertForQuestionAnswering(config).state_dict()`: the encoder under `lxmert.` + the answer head."""
+    H = cfg["hidden_size"]
+    return [("lxmert." + k, s) for k, s in lxmert_param_spec(cfg)] + [
+        ("answer_head.logit_fc.0.weight", (2 * H, H)), ("answer_head.logit_fc.0.bias", (2 * H,)),
+        ("answer_head.logit_fc.2.weight", (2 * H,)), ("answer_head.logit_fc.2.bias", (2 * H,)),
+        ("answer_head.logit_fc.3.weight", (num_qa_labels, 2 * H)), ("answer_head.logit_fc.3.bias", (num_qa_labels,))]
+
+
+def make_lxmert_qa_state_dict(cfg, num_qa_labels, seed=0):
+    sd = {"lxmert." + k: v for k, v in make_lxmert_state_dict(cfg, seed).items()}
+    for name, shape in lxmert_qa_param_spec(cfg, num_qa_labels)[-6:]:
+        g = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+        sd[name] = (g.uniform(0.5, 1.5, shape) if name.endswith("fc.2.weight") else g.standard_normal(shape) * 0.05).astype(np.float32)
+    return sd
+
+
 def make_lxmert_state_dict(cfg, seed=0):
     """Seeded synthetic weights (no checkpoint can be fetched offline): BERT-style N(0, 0.05) matrices (wider than the
     0.02 init so every layer matters in a parity check), LayerNorm gamma ~ U(0.5, 1.5), small biases."""
@@ -318,3 +335,40 @@ class LxmertEncoder:
         L.call("vk_conv2d", lang.data_ptr(), B, Lq, 1, H, w.data_ptr(), bb.data_ptr(), None, pooled.data_ptr(), H, H, 1, 1, Lq, 0, 1, 1,
                L.VK_ACT_TANH, self.dt, self.dt, self._stream())
         return lang.view(B, Lq, H), visn.view(B, V, H), pooled
+
+
+class LxmertForQuestionAnswering:
+    """`transformers.LxmertForQuestionAnswering` (modeling_lxmert.py :1123-1290, the VQA/GQA model of BASELINE config 5) on the
+    HIP path: encoder + `LxmertVisualAnswerHead` :602-614 (Linear -> GELU -> LayerNorm -> Linear on the pooled output).
+    `model(...)` returns `question_answering_score [B, num_qa_labels]` (storage dtype)."""
+
+    def __init__(self, config, num_qa_labels, precision="bf16", device="cuda:0"):
+        self.lxmert = LxmertEncoder(config, precision, device)
+        self.num_qa_labels = int(num_qa_labels)
+
+    def load_state_dict(self, sd, strict=True):
+        sd = {k: (v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)) for k, v in sd.items()}
+        want = dict(lxmert_qa_param_spec(self.lxmert.cfg, self.num_qa_labels))
+        if strict and set(want) != set(sd):
+            raise RuntimeError(f"LxmertForQuestionAnswering.load_state_dict: missing {sorted(set(want) - set(sd))[:4]} "
+                               f"unexpected {sorted(set(sd) - set(want))[:4]}")
+        enc = self.lxmert
+        enc.load_state_dict({k[len("lxmert."):]: v for k, v in sd.items() if k.startswith("lxmert.")}, strict)
+        enc._lin["answer.fc0"] = enc._pack(sd["answer_head.logit_fc.0.weight"], sd["answer_head.logit_fc.0.bias"])
+        enc._lin["answer.fc3"] = enc._pack(sd["answer_head.logit_fc.3.weight"], sd["answer_head.logit_fc.3.bias"])
+        enc._ln["answer.ln"] = (torch.from_numpy(sd["answer_head.logit_fc.2.weight"]).to(enc.device),
+                                torch.from_numpy(sd["answer_head.logit_fc.2.bias"]).to(enc.device))
+        return self
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def __call__(self, input_ids, visual_feats, visual_pos, attention_mask=None, visual_attention_mask=None, token_type_ids=None):
+        enc = self.lxmert
+        _, _, pooled = enc._forward(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids)
+        h = enc._linear(pooled, "answer.fc0", act=L.VK_ACT_GELU)
+        h = enc._layernorm(h, "answer.ln")
+        score = enc._linear(h, "answer.fc3")
+        torch.cuda.synchronize(enc.device)
+        return score
