@@ -40,6 +40,21 @@ KERNEL_NAMES = {   # kernel_timing() bucket -> (rocprofv3 kernel name, descripti
 }
 
 
+def stage_fractions(st, B, R, arch):
+    """Per stage of the forward: ms, algorithmic TFLOP/s and fraction of the f16 MFMA peak (backbone and whole
+    model are asked for separately); the index stages (proposals, outputs) are latency-bound: ms only."""
+    gf = {"backbone": (943.5 if arch == "x152" else 292.4) * B, "rpn_head": 40.0 * B,
+          "roi_heads": (11.25 if arch == "x152" else 5.857) * R * B}
+    out = {}
+    for k, ms in st.items():
+        e = {"ms": round(float(ms), 3)}
+        if k in gf and ms > 0:
+            e["tflops"] = round(gf[k] / ms, 1)
+            e["frac_of_mfma_peak"] = round(gf[k] / ms / PEAK_F16_TFLOPS, 4)
+        out[k] = e
+    return out
+
+
 def pmc_traffic(batch, proposals, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
@@ -125,6 +140,7 @@ def main():
     for _ in range(a.warmup):
         step()
     model.enable_kernel_timing(True)
+    model.enable_stage_timing(True)
     model.kernel_timing(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -137,6 +153,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kt = model.kernel_timing()
+    st = model.stage_timing_ms()                 # HIP events of the LAST step's stages (backbone / RPN head / proposals / RoI heads / outputs)
     assert out["roi_features"].shape[0] == world * B
 
     if rank == 0:
@@ -167,6 +184,7 @@ def main():
                                         {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                         for k, v in kt.items() if v["ms"] > 0},
+                         "stages_last_step": stage_fractions(st, B, a.proposals, a.arch),
                          "all_conv_kernels": {"ms_per_step": round(all_ms / a.steps, 3),
                                               "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
                                               "share_of_step": round(all_ms / (dt * 1e3), 4)}},
