@@ -7,8 +7,8 @@ register (loop back-edges and exits, operand set-up of a tied asm operand behind
 `v_mov` of a register whose read may not have landed yet -- stale data, timing dependent, found on MI355X as
 rare wrong 16-row blocks.  The kernels are therefore written so that every loop boundary and branch follows an
 `s_waitcnt lgkmcnt(0)`; this script proves it on the compiled code: it compiles each source to assembly, replays
-the LDS read queue (reads return in order; `lgkmcnt(N)` retires all but the N newest) and reports every
-instruction that touches a register with a pending read.
+the LDS read queue (reads return in order; `lgkmcnt(N)` retires all but the N newest) and the queue of global loads into
+registers (`vmcnt`), and reports every instruction that touches a register with a pending read.
 
 usage: python tools/check_asm_hazards.py [file.hip ...]      exit code 1 if any hazard is found
 """
@@ -35,8 +35,13 @@ def _regs(tok):
 
 def scan_function(lines):
     """lines: the instructions of one kernel.  Returns [(line_no, text, pending_read_line)]."""
-    pend, found = [], []
+    pend, vpend, found = [], [], []          # in-flight LDS reads / in-flight global loads into registers (not LDS-DMA)
+    in_asm = False                           # only HAND-ISSUED loads are tracked: hipcc waits correctly for its own
     for i, raw in enumerate(lines):
+        if "#ASMSTART" in raw:
+            in_asm = True
+        elif "#ASMEND" in raw:
+            in_asm = False
         t = raw.split(";")[0].strip()
         if not t or t.endswith(":") or t.startswith("."):
             continue
@@ -44,22 +49,35 @@ def scan_function(lines):
         op, args = parts[0], (parts[1] if len(parts) > 1 else "")
         ops = [a.strip() for a in args.split(",")]
         if op.startswith("ds_read"):
-            pend.append((i, set(_regs(ops[0]))))
+            if in_asm:
+                pend.append((i, set(_regs(ops[0]))))
             continue
-        m = re.match(r"s_waitcnt.*lgkmcnt\((\d+)\)", t)
-        if m:
-            n = int(m.group(1))
-            if n == 0:
-                pend = []
-            elif n < len(pend):
-                pend = pend[len(pend) - n:]
+        if re.match(r"(global|buffer|flat)_load", op) and "_lds_" not in op and " lds" not in t:
+            if in_asm:
+                vpend.append((i, set(_regs(ops[0]))))
+            continue
+        if op.startswith("s_waitcnt"):
+            m = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    pend = []
+                elif n < len(pend):
+                    pend = pend[len(pend) - n:]
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:          # other VMEM ops (LDS-DMA, stores) also count, so fewer of OUR loads may be pending than n: n == 0 is exact,
+                n = int(m.group(1))     # n > 0 conservatively keeps the newest n loads pending
+                if n == 0:
+                    vpend = []
+                elif n < len(vpend):
+                    vpend = vpend[len(vpend) - n:]
             continue
         if op.startswith("s_"):
             continue
         used = set()
         for a in ops:
             used |= set(_regs(a))
-        for li, rs in pend:
+        for li, rs in pend + vpend:
             if used & rs:
                 found.append((i, t, li))
     return found
