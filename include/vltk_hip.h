@@ -159,9 +159,12 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
  * bucket 0: conv_mfma256_kernel (256x256 LDS-ring tile)          1: conv_mfma_kernel f16->f16 (128x{64,128} tile)
  * bucket 2: conv_mfma_kernel f16->f32 out (RPN heads, predictor)  3: f32 strict-mode convs / stem
  * bucket 4: conv3x3_panel_kernel (3x3, LDS-resident input panel)  5: conv_duo_kernel (1x1, 128x256 tile, two per CU)
- * launches[6], ms[6], flops[6] (algorithmic 2*M*Cout*K of the launches), bytes[6] (algorithmic HBM bytes:
+ * bucket 6: any conv kernel launched in the two-stream section of the backbone (res3 / res4 half-batches): these launches
+ *           overlap each other in time, so their summed durations exceed the wall time they took -- kept apart so that the
+ *           buckets above hold only launches that had the GPU to themselves
+ * launches[7], ms[7], flops[7] (algorithmic 2*M*Cout*K of the launches), bytes[7] (algorithmic HBM bytes:
  * input + output (+ residual) + weights, each once). */
-#define VK_NUM_KERNEL_BUCKETS 6
+#define VK_NUM_KERNEL_BUCKETS 7
 int vk_enable_kernel_timing(vk_handle *h, int enable);
 int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 

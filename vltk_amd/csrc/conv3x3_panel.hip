@@ -79,7 +79,8 @@ __device__ __forceinline__ void vm_wait() {
 }
 
 // DBG: timing-only diagnostic builds (VK_CONV256_DBG): 1 = no tap-validity masking (WRONG results)
-template <int PP, int DBG>
+// TAG 1: second symbol for launches of the two-stream backbone section (see conv_mfma_duo.hip)
+template <int PP, int DBG, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PROWS = PP * 128;               // panel rows
@@ -427,6 +428,10 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64 + P_NW * P_WSLOT));
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 0, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<4, 0, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64 + P_NW * P_WSLOT));
         attr_set = true;
     }
     PanelK k;
@@ -462,14 +467,18 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
     if (panel_pp(a) == 3 && dbg == 1)
         hipLaunchKernelGGL((conv3x3_panel_kernel<3, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    else if (panel_pp(a) == 3 && a.concurrent)
+        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
     else if (panel_pp(a) == 3)
         hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    else if (a.concurrent)
+        hipLaunchKernelGGL((conv3x3_panel_kernel<4, 0, 1>), grid, block, 2 * 4 * 128 * 64 + P_NW * P_WSLOT, stream, k);
     else
         hipLaunchKernelGGL((conv3x3_panel_kernel<4, 0>), grid, block, 2 * 4 * 128 * 64 + P_NW * P_WSLOT, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({4, 2.0 * (double)k.M * a.Cout * 9 * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 9, 1,
+        tm->recs.push_back({a.concurrent ? 6 : 4, 2.0 * (double)k.M * a.Cout * 9 * a.Cin, e0, e1, k.M, a.Cout, a.Cin, 9, 1,
                             2.0 * ((double)k.M * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * 9 * a.Cin)});
     }
     return VK_OK;

@@ -43,6 +43,7 @@ struct ConvK {
     int ldy;
     int kw, stride, pad, dil;
     int ktiles, kt_per_tap;
+    int concurrent;      // timing bucket 6 (two-stream section)
     int slice_bytes;     // grouped conv: bytes of the input-channel slice a 64-channel output tile reads (0: dense)
     int wrow_bytes;      // ktiles * 128
     int relu;
@@ -360,6 +361,7 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         int bucket = 3;
         if (sizeof(T) == 2 && !STEM) bucket = sizeof(OutT) == 4 ? 2 : 1;
+        if (k.concurrent) bucket = 6;
         tm->recs.push_back({bucket, k.alg_flops, e0, e1, k.M, k.cout8, k.cin_bytes / (int)sizeof(T), k.ktiles / k.kt_per_tap, k.stride, k.alg_bytes});
     }
     return VK_OK;
@@ -408,6 +410,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     k.pad = a.pad;
     k.dil = a.dil;
     k.relu = a.relu;
+    k.concurrent = a.concurrent;
     k.slice_bytes = 0;
     if (a.stem) {
         VK_REQUIRE(a.Cin == 4 && a.kh == 7 && a.kw == 7 && a.stride == 2, VK_EINVAL, "conv: stem mode is 7x7 s2 on NHWC4");

@@ -500,7 +500,7 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride,
+        tm->recs.push_back({a.concurrent ? 6 : 0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride,
                             2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) +
                                    (double)a.Cout * a.kh * a.kw * a.Cin)});
     }

@@ -126,6 +126,8 @@ struct vk_handle {
     KernelTimer *ktimer = nullptr;
     bool timing = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side = nullptr;                     // second stream of the res4 stage (half-batch pipelining)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ev_valid = false;
 };
 
@@ -414,9 +416,10 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
 
 static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int H, int W, const void *res, void *y,
                     bool relu, vk_dtype out_dt, int ldy, hipStream_t s, int *Ho = nullptr, int *Wo = nullptr,
-                    const void *x2 = nullptr, int cin2 = 0, float *pool_part = nullptr) {
+                    const void *x2 = nullptr, int cin2 = 0, float *pool_part = nullptr, bool concurrent = false) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    a.concurrent = concurrent ? 1 : 0;
     a.x = x;
     a.x2 = x2;
     a.Cin2 = cin2;
@@ -447,19 +450,35 @@ static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int 
 }
 
 // BottleneckBlock.forward frcnn.py:963-979.  x [N,H,W,cin] -> y [N,Ho,Wo,cout]
+// n0 / nb: run images [n0, n0 + nb) of the full-batch buffers (every buffer is [N, H, W, C]: the half-batch pointers are
+// plain offsets).  nb < 0: the whole batch.
 static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, int W, void *t1, void *t2, void *sc,
-                     void *y, hipStream_t s, int *Ho, int *Wo, float *pool_part = nullptr) {
+                     void *y, hipStream_t s, int *Ho, int *Wo, float *pool_part = nullptr, int n0 = 0, int nb = -1) {
     int h1, w1, h2, w2;
+    const bool cc = nb >= 0;            // half-batch beside the other half on a second stream
+    if (nb >= 0) {
+        const size_t es = dtype_size(h->dt);
+        int ho, wo;
+        conv_out_hw(H, W, b.conv1.k, b.conv1.stride, b.conv1.pad, b.conv1.dil, &h1, &w1);
+        conv_out_hw(h1, w1, b.conv2.k, b.conv2.stride, b.conv2.pad, b.conv2.dil, &h2, &w2);
+        conv_out_hw(h2, w2, 1, 1, 0, 1, &ho, &wo);
+        x = (const char *)x + (size_t)n0 * H * W * b.conv1.cin * es;
+        t1 = (char *)t1 + (size_t)n0 * h1 * w1 * b.conv1.cout * es;
+        t2 = (char *)t2 + (size_t)n0 * h2 * w2 * b.conv2.cout * es;
+        sc = (char *)sc + (size_t)n0 * ho * wo * b.conv3.cout * es;
+        y = (char *)y + (size_t)n0 * ho * wo * b.conv3.cout * es;
+        N = nb;
+    }
     const void *res = x;
     if (b.has_shortcut && !b.fused_shortcut) {
-        VK_TRY(run_conv(h, b.shortcut, x, N, H, W, nullptr, sc, false, h->dt, 0, s));
+        VK_TRY(run_conv(h, b.shortcut, x, N, H, W, nullptr, sc, false, h->dt, 0, s, nullptr, nullptr, nullptr, 0, nullptr, cc));
         res = sc;
     }
-    VK_TRY(run_conv(h, b.conv1, x, N, H, W, nullptr, t1, true, h->dt, 0, s, &h1, &w1));
-    VK_TRY(run_conv(h, b.conv2, t1, N, h1, w1, nullptr, t2, true, h->dt, 0, s, &h2, &w2));
+    VK_TRY(run_conv(h, b.conv1, x, N, H, W, nullptr, t1, true, h->dt, 0, s, &h1, &w1, nullptr, 0, nullptr, cc));
+    VK_TRY(run_conv(h, b.conv2, t1, N, h1, w1, nullptr, t2, true, h->dt, 0, s, &h2, &w2, nullptr, 0, nullptr, cc));
     if (b.fused_shortcut)      // stride-1 block: t2 and x cover the same pixels
-        return run_conv(h, b.conv3, t2, N, h2, w2, nullptr, y, true, h->dt, 0, s, Ho, Wo, x, b.shortcut.cin, pool_part);
-    VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo, nullptr, 0, pool_part));
+        return run_conv(h, b.conv3, t2, N, h2, w2, nullptr, y, true, h->dt, 0, s, Ho, Wo, x, b.shortcut.cin, pool_part, cc);
+    VK_TRY(run_conv(h, b.conv3, t2, N, h2, w2, res, y, true, h->dt, 0, s, Ho, Wo, nullptr, 0, pool_part, cc));
     return VK_OK;
 }
 
@@ -944,6 +963,9 @@ int vk_destroy(vk_handle *h) {
     if (h->arena) (void)hipFree(h->arena);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     delete h->ktimer;
     delete h;
     return VK_OK;
@@ -1030,14 +1052,39 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
                      p.img_pad, p.stem_out, s));
     void *cur = p.bufA, *nxt = p.bufB;
     int ch = p.Hs[0], cw = p.Ws[0];
-    for (int st = 0; st < 3; ++st)
+    // res4 at batch 32 is 2.05 rounds of tiles on 256 CUs: every N = 256 layer pays 3 rounds.  Its two half-batches run on
+    // two streams, so the tail of one half's layer k overlaps the other half's layer k (images are independent; the
+    // halves touch disjoint parts of every buffer).  VK_BACKBONE_STREAMS=1 disables it (A/B).
+    static const bool two_streams = !(getenv("VK_BACKBONE_STREAMS") && getenv("VK_BACKBONE_STREAMS")[0] == '1');
+    for (int st = 0; st < 3; ++st) {
+        const bool split = two_streams && st >= 1 && N >= 8 && h->dt == VK_F16;
+        if (split) {
+            if (!h->side) {
+                VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+                VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            }
+            VK_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+            VK_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        }
+        const int na = split ? N / 2 : N;
         for (auto &b : h->stages[st]) {
             int ho, wo;
-            VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo));
+            if (split) {
+                VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo, nullptr, 0, na));
+                VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, h->side, &ho, &wo, nullptr, na, N - na));
+            } else {
+                VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo));
+            }
             std::swap(cur, nxt);
             ch = ho;
             cw = wo;
         }
+        if (split) {
+            VK_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+            VK_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        }
+    }
     VK_REQUIRE(ch == p.Hf && cw == p.Wf, VK_EINVAL, "internal: res4 geometry mismatch (%dx%d vs %dx%d)", ch, cw, p.Hf, p.Wf);
     const void *res4 = cur;
     set_stage(h, "res4", res4, h->dt, {N, p.Hf, p.Wf, h->res4_c});

@@ -66,6 +66,7 @@ struct ConvArgs {
     int Ho, Wo, Cout, ldy;
     int kh, kw, stride, pad, dil;
     int groups;          // 0 / 1: dense; > 1: slice-diagonal weights (vk_pack_conv_weight), Cin == Cout
+    int concurrent;      // launched beside another stream's kernels (timing bucket 6)
     float *pool_part;    // fused spatial mean (Res5 `.mean(dim=[2,3])`): per-tile column sums go here, y is not written
     const void *x2;      // dual-source 1x1 (conv3 + projection shortcut in one GEMM): second input [M, Cin2], K = Cin | Cin2
     int Cin2;
