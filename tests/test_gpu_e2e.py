@@ -204,6 +204,26 @@ def test_chunking_and_determinism(setup):
                 assert torch.equal(ref[k], cur[k]), (k, chunk)
 
 
+def test_two_stream_backbone_is_bit_identical(setup):
+    """res3/res4 as two half-batches on two HIP streams (the bench-size default) against the single-stream order: every
+    output and the res4 map are bit-identical, for an even and an odd batch."""
+    cfg, sd, x, shapes = setup
+    m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
+    m.set_option("backbone_split_min_batch", 2)
+    for reps in (2, (3, 1)):
+        xs = torch.cat([x] * reps) if isinstance(reps, int) else torch.cat([x, x, x[:1]])
+        sh = torch.tensor(shapes * reps) if isinstance(reps, int) else torch.tensor(shapes + shapes + shapes[:1])
+        outs = []
+        for streams in (1, 2, 2):
+            m.set_option("backbone_streams", streams)
+            m(xs, sh)
+            o = {k: v.clone() for k, v in m.forward_padded().items()}
+            o["res4"] = m.get_stage("res4").clone()
+            outs.append(o)
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), k
+
+
 def test_call_surface_like_reference_test(setup):
     """Counterpart of the reference's tests/frcnn_test.py:15-31 (call shape + mutable roi_outputs attributes)."""
     cfg, sd, x, shapes = setup

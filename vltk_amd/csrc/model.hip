@@ -114,6 +114,8 @@ struct vk_handle {
     char *arena = nullptr;
     size_t arena_bytes = 0;
     int head_chunk = 9600;                           // RoIs per Res5 chunk (vk_set_option "head_chunk")
+    int backbone_streams = 2;                        // 2: res3/res4 as two half-batches on two streams (option "backbone_streams")
+    int backbone_split_min_batch = 8;                // ... from this batch size on (option "backbone_split_min_batch")
 
     // stage bookkeeping of the last forward
     struct Stage {
@@ -781,6 +783,8 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     h->dt = (vk_dtype)cfg->precision;
     const char *env = getenv("VK_HEAD_CHUNK");
     if (env && atoi(env) > 0) h->head_chunk = atoi(env);
+    if (const char *bs = getenv("VK_BACKBONE_STREAMS"))
+        if (bs[0] == '1' || bs[0] == '2') h->backbone_streams = bs[0] - '0';
     const int di = cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2);
     add_conv_names(h->names, "backbone.stem.conv1", true);
     h->stem = ConvLayer{"backbone.stem.conv1", 3, cfg->stem_out_channels, 7, 2, 3, 1, true, true};
@@ -952,6 +956,16 @@ int vk_set_option(vk_handle *h, const char *key, int value) {
         h->head_chunk = value;
         return VK_OK;
     }
+    if (!strcmp(key, "backbone_streams")) {
+        VK_REQUIRE(value == 1 || value == 2, VK_EINVAL, "backbone_streams must be 1 or 2");
+        h->backbone_streams = value;
+        return VK_OK;
+    }
+    if (!strcmp(key, "backbone_split_min_batch")) {
+        VK_REQUIRE(value >= 2, VK_EINVAL, "backbone_split_min_batch must be >= 2");
+        h->backbone_split_min_batch = value;
+        return VK_OK;
+    }
     VK_REQUIRE(false, VK_EINVAL, "unknown option '%s'", key);
 }
 
@@ -1054,10 +1068,9 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
     int ch = p.Hs[0], cw = p.Ws[0];
     // res4 at batch 32 is 2.05 rounds of tiles on 256 CUs: every N = 256 layer pays 3 rounds.  Its two half-batches run on
     // two streams, so the tail of one half's layer k overlaps the other half's layer k (images are independent; the
-    // halves touch disjoint parts of every buffer).  VK_BACKBONE_STREAMS=1 disables it (A/B).
-    static const bool two_streams = !(getenv("VK_BACKBONE_STREAMS") && getenv("VK_BACKBONE_STREAMS")[0] == '1');
+    // halves touch disjoint parts of every buffer).  Option "backbone_streams" = 1 / VK_BACKBONE_STREAMS=1 disables it.
     for (int st = 0; st < 3; ++st) {
-        const bool split = two_streams && st >= 1 && N >= 8 && h->dt == VK_F16;
+        const bool split = h->backbone_streams == 2 && st >= 1 && N >= 2 && N >= h->backbone_split_min_batch && h->dt == VK_F16;
         if (split) {
             if (!h->side) {
                 VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
