@@ -73,6 +73,63 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x,
     }
 }
 
+// 16-byte-vector form of layernorm_kernel for rows whose length is a multiple of 8 elements (2-byte types) / 4 (f32): a lane owns
+// chunks lane, lane + 64, ... of the row.  Same arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T *__restrict__ x, int ldx, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, T *__restrict__ y, int ldy, int M, int C,
+                                                           float eps, float scale, int accumulate) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    constexpr int MAXC = LN_MAX_PER_LANE / V;          // chunks per lane
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int chunks = C / V;
+    float v[MAXC][V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < chunks) {
+            const vecT t = *reinterpret_cast<const vecT *>(x + (long)row * ldx + ch * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                v[i][e] = (float)t[e];
+                s += v[i][e];
+            }
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < chunks) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < chunks) {
+            T *yp = y + (long)row * ldy + ch * V;
+            vecT o;
+            vecT old;
+            if (accumulate) old = *reinterpret_cast<const vecT *>(yp);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float r = ((v[i][e] - mean) * rstd * gamma[ch * V + e] + beta[ch * V + e]) * scale;
+                if (accumulate) r += (float)old[e];
+                o[e] = (T)r;
+            }
+            *reinterpret_cast<vecT *>(yp) = o;
+        }
+    }
+}
+
 // One workgroup per (batch b, head h).  Q, K, V of the head are staged in LDS as fp32 (rows padded by one float so
 // that column walks do not collide on a bank); 256 threads share the Lq x Lk scores, one wave per row does the
 // soft-max, then the threads share the Lq x d outputs.  Scores, soft-max and the weighted sum are fp32 (the
@@ -86,14 +143,36 @@ __global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ q,
     const int dp = d + 1, lp = Lk + 1;
     float *qs = sm, *ks = qs + Lq * dp, *vs = ks + Lk * dp, *ps = vs + Lk * d;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
-    for (int i = tid; i < Lk * d; i += 256) {
-        const int r = i / d, c = i - r * d;
-        ks[r * dp + c] = ldf(k + ((long)b * Lk + r) * ldk + h * d + c);
-        vs[i] = ldf(v + ((long)b * Lk + r) * ldv + h * d + c);
-    }
-    for (int i = tid; i < Lq * d; i += 256) {
-        const int r = i / d, c = i - r * d;
-        qs[r * dp + c] = ldf(q + ((long)b * Lq + r) * ldq + h * d + c);
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(V)));
+    if (d % V == 0 && ldq % V == 0 && ldk % V == 0 && ldv % V == 0) {       // 16-byte staging loads
+        const int dv = d / V;
+        for (int i = tid; i < Lk * dv; i += 256) {
+            const int r = i / dv, c = (i - r * dv) * V;
+            const vecT kk = *reinterpret_cast<const vecT *>(k + ((long)b * Lk + r) * ldk + h * d + c);
+            const vecT vv = *reinterpret_cast<const vecT *>(v + ((long)b * Lk + r) * ldv + h * d + c);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                ks[r * dp + c + e] = (float)kk[e];
+                vs[r * d + c + e] = (float)vv[e];
+            }
+        }
+        for (int i = tid; i < Lq * dv; i += 256) {
+            const int r = i / dv, c = (i - r * dv) * V;
+            const vecT qq = *reinterpret_cast<const vecT *>(q + ((long)b * Lq + r) * ldq + h * d + c);
+#pragma unroll
+            for (int e = 0; e < V; ++e) qs[r * dp + c + e] = (float)qq[e];
+        }
+    } else {
+        for (int i = tid; i < Lk * d; i += 256) {
+            const int r = i / d, c = i - r * d;
+            ks[r * dp + c] = ldf(k + ((long)b * Lk + r) * ldk + h * d + c);
+            vs[i] = ldf(v + ((long)b * Lk + r) * ldv + h * d + c);
+        }
+        for (int i = tid; i < Lq * d; i += 256) {
+            const int r = i / d, c = i - r * d;
+            qs[r * dp + c] = ldf(q + ((long)b * Lq + r) * ldq + h * d + c);
+        }
     }
     __syncthreads();
     for (int i = tid; i < Lq * Lk; i += 256) {
@@ -132,6 +211,12 @@ template <typename T>
 static int ln_launch(const void *x, int ldx, const float *g, const float *b, void *y, int ldy, int M, int C, float eps, float scale,
                      int accumulate, const int64_t *ids, const int64_t *tts, const void *pos, const void *typ, int L, hipStream_t s) {
     const dim3 grid((M + 3) / 4), block(256);
+    constexpr int V = 16 / sizeof(T);
+    if (!ids && C % V == 0 && ldx % V == 0 && ldy % V == 0) {
+        hipLaunchKernelGGL((layernorm_vec_kernel<T>), grid, block, 0, s, (const T *)x, ldx, g, b, (T *)y, ldy, M, C, eps, scale, accumulate);
+        VK_CHECK_HIP(hipGetLastError());
+        return VK_OK;
+    }
     if (ids)
         hipLaunchKernelGGL((layernorm_kernel<T, true>), grid, block, 0, s, (const T *)x, ldx, g, b, (T *)y, ldy, M, C, eps, scale, accumulate,
                            ids, tts, (const T *)pos, (const T *)typ, L);
