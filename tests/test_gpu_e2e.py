@@ -224,6 +224,26 @@ def test_two_stream_backbone_is_bit_identical(setup):
             assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), k
 
 
+def test_two_stream_head_is_bit_identical(setup):
+    """Each Res5 chunk as two half-chunks on two HIP streams (option head_streams = 2) against the single-stream order:
+    bit-identical outputs and pooled features, for one chunk and for ragged chunks (odd halves)."""
+    cfg, sd, x, shapes = setup
+    m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
+    m.set_option("head_split_min_rois", 2)
+    sh = torch.tensor(shapes)
+    for chunk in (0, 23):
+        m.set_option("head_chunk", chunk)
+        outs = []
+        for streams in (1, 2, 2):
+            m.set_option("head_streams", streams)
+            m(x, sh)
+            o = {k: v.clone() for k, v in m.forward_padded().items()}
+            o["feature_pooled"] = m.get_stage("feature_pooled").clone()
+            outs.append(o)
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), (k, chunk)
+
+
 def test_call_surface_like_reference_test(setup):
     """Counterpart of the reference's tests/frcnn_test.py:15-31 (call shape + mutable roi_outputs attributes)."""
     cfg, sd, x, shapes = setup
