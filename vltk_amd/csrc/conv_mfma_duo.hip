@@ -82,9 +82,16 @@ constexpr int d_smem(int XS) { return XS * D_XB + D_NSLOT * D_WB; }
 
 // STAMP: diagnostic build (VK_DUO_STAMPS=<file>): wave 0 records s_memrealtime at the phase boundaries into a
 // buffer nothing else reads (cdna guide section 7, in-kernel stamps); never used by the product path.
-// DBG 1 (timing-only STAMP build, WRONG results): weight pieces not requested (2 instead of 6 LDS-DMA instructions per
-// wave and stage): 1638 -> 1279 cycles per stage on Res5 conv1, i.e. ~90 cycles of issue per LDS-DMA piece; the same
-// four loads as compiler-tracked global_load_dwordx4 into registers were slower (1869), so the pieces stay DMA
+// DBG: ablation bit mask (timing-only STAMP builds, WRONG results; VK_DUO_DBG with VK_DUO_STAMPS): 1 no weight DMA, 2 no pixel
+// DMA after the prologue, 4 no fragment ds_reads, 8 no MFMAs.  Core cycles per 32-MFMA stage on Res5 conv3 (K = 512, one
+// wave, partner workgroup mostly in its epilogue): full 1432 | no weight DMA 1217 | no DMA 1092 | no ds_reads 1316 | MFMA
+// only 938 | no MFMA 1272 | ds_reads only 650 | DMA only 1240.  The six LDS-DMA pieces alone take 1240 cycles: 24 KiB per
+// stage and workgroup = 20 B/clk/CU, plus the partner's epilogue traffic on the same vector-memory path, against the
+// ~33 B/clk/CU the L2 -> LDS path delivers at best (MI355X_MICROARCH.md, gather into LDS): a 128 x 256 tile is bound by
+// operand fill ((128 + 256) x 64 B per stage), not by MFMA issue.  An eight-wave build (two waves per SIMD and
+// workgroup, 128 x 32 per wave, <= 128 VGPRs) was correct and SLOWER (941 vs 760 us: 1812 cycles per stage, 28 % at the
+// barrier): more issuing waves do not raise the fill rate.  Weights as compiler-tracked global_load_dwordx4 into
+// registers were slower too (1869 cycles on Res5 conv1), so the pieces stay DMA
 // GELU: the erf-form GELU epilogue (encoder FFN) is a separate instantiation: sixteen inlined erff() in the epilogue of
 // every build cost the detector 16 % (instruction footprint), measured
 // TAG 1: the same code under a second symbol for launches of the two-stream backbone section, so that profilers list the
@@ -136,13 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
         const bool second = stage >= p.split;                        // uniform
         unsigned a = second ? a2_off[i] : a_off[i];
         asm volatile("" : "+v"(a));     // opaque: keeps the add in the loop instead of a register per (stage, piece)
+        if constexpr ((DBG & 2) != 0)
+            if (stage >= XS) return;                                 // ablation: no pixel DMA after the prologue
         const char *base = second ? p.x2 : p.x;
         VKD_GLDS16(base + (a + (unsigned)(stage - (second ? p.split : 0)) * 64u), smem + slot * D_XB + (wave * 2 + i) * 1024);
     };
     auto req_w = [&](int stage, int slot, int i) {
         unsigned a = wsrc0;
         asm volatile("" : "+v"(a));
-        if constexpr (DBG == 1) return;
+        if constexpr ((DBG & 1) != 0) return;                        // ablation: no weight DMA
         VKD_GLDS16(p.w + (a + i * wstep + (unsigned)stage * 64u), smem + D_WBASE + slot * D_WB + (wave * 4 + i) * 1024);
     };
 
@@ -166,12 +175,17 @@ __global__ __launch_bounds__(256, 2) void conv_duo_kernel(DuoK p) {
 
     // hand-issued fragment reads with counted waits (see conv_mfma256.hip: hipcc would wait lgkmcnt(0) at
     // every use while an LDS-DMA is in flight)
-#define VKD_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define VKD_DSR(dst, addr, OFF)                                                               \
+    do {                                                                                      \
+        if constexpr ((DBG & 4) != 0) asm volatile("" : "=v"(dst) : "v"(addr));               \
+        else asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr));        \
+    } while (0)
 #define VKD_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
 #define VKD_SB() __builtin_amdgcn_sched_barrier(0)
 #define VKD_MMA_ROW(MI, XR, WF)                                                                      \
     do {                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                               \
+        if constexpr ((DBG & 8) == 0)                                                                \
         _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[MI][ni] =                               \
             DuoT<ET>::mfma(WF[ni], XR, acc[MI][ni]);                                              \
         __builtin_amdgcn_s_setprio(0);                                                               \
@@ -562,8 +576,10 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, true, 3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, true, 3, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)));
+#define VKD_DBG_ATTR(D) VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_duo_kernel<_Float16, true, 3, D>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, d_smem(3)))
+        VKD_DBG_ATTR(1); VKD_DBG_ATTR(3); VKD_DBG_ATTR(4); VKD_DBG_ATTR(7); VKD_DBG_ATTR(8); VKD_DBG_ATTR(11); VKD_DBG_ATTR(12);
+#undef VKD_DBG_ATTR
         attr_set = true;
     }
     DuoK k;
@@ -609,8 +625,10 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
         const size_t nb = (size_t)grid.x * 12 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
         const int dbg = getenv("VK_DUO_DBG") ? atoi(getenv("VK_DUO_DBG")) : 0;
-        if (dbg == 1)
-            hipLaunchKernelGGL((conv_duo_kernel<_Float16, true, 3, 1>), grid, block, d_smem(3), stream, k);
+        if (false) {}
+#define VKD_DBG_RUN(D) else if (dbg == D) hipLaunchKernelGGL((conv_duo_kernel<_Float16, true, 3, D>), grid, block, d_smem(3), stream, k)
+        VKD_DBG_RUN(1); VKD_DBG_RUN(3); VKD_DBG_RUN(4); VKD_DBG_RUN(7); VKD_DBG_RUN(8); VKD_DBG_RUN(11); VKD_DBG_RUN(12);
+#undef VKD_DBG_RUN
         else
             hipLaunchKernelGGL((conv_duo_kernel<_Float16, true, 3>), grid, block, d_smem(3), stream, k);
         VK_CHECK_HIP(hipStreamSynchronize(stream));
