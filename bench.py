@@ -6,7 +6,8 @@
 
 A step = one vk_forward over one per-GPU batch of synthetic 800x1333 images already resident in HBM
 (ResNet-101-C4 fp16, R = 300 RPN proposals through the Res5 head, up to 100 detections per image),
-followed -- for N > 1 -- by the all-gather of the output blocks (RCCL).  Images shard across ranks
+followed -- for N > 1 -- by ONE all-gather of the flat output block (RCCL), overlapped with the next step's forward and
+completed inside the timed region.  Images shard across ranks
 (weak scaling: fixed per-GPU batch).  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -105,6 +106,14 @@ def main():
                     help="r101 = the BASELINE workload (configs[1]); x152 = ResNeXt-152 32x8d (SURVEY.md 8d config c4, extra)")
     a = ap.parse_args()
 
+    # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With RCCL's streams alive, the forward's second
+    # stream (res3/res4 half-batches) lands on the main stream's queue and the halves serialise: measured 374 instead of
+    # 402 images/s on one GPU with a one-rank RCCL group; 16 queues restore it.  Must be set before HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # RCCL prints a version banner on stdout at communicator creation: keep stdout for the ONE JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -112,12 +121,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or os.environ.get("VLTK_AMD_FORCE_COLLECTIVE") == "1"     # the latter: one-rank RCCL group (validation)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
-    from vltk_amd.parallel import gather_outputs
+    from vltk_amd.parallel import gather_outputs_async
     arch = dict(depth=152, num_groups=32, width_per_group=8) if a.arch == "x152" else {}
     cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}", **arch)
     sd = make_state_dict(cfg, seed=1234)
@@ -128,27 +141,50 @@ def main():
     images = torch.from_numpy(synthetic_images(B, 800, 1333, seed=0xF2C, rank=rank)).cuda(local_rank)
     shapes = torch.tensor([[800, 1333]] * B)
 
+    pending = []
+    gbuf = {}          # rotating destinations of the gathers in flight (allocated once)
+
+    def step_gather(i):
+        blk = model.forward_padded()
+        if use_pg and i % 3 not in gbuf:
+            gbuf[i % 3] = torch.empty(dist.get_world_size() * blk.flat.numel(), dtype=torch.uint8, device=blk.flat.device)
+        return gather_outputs_async(blk, out=gbuf.get(i % 3))
+
+    nstep = [0]
+
     def step():
+        # the all-gather of step i (one collective over the flat output block, RCCL's own stream) runs under the
+        # forward of step i+1; every gather is waited for inside the timed region (drain() before the closing barrier)
         model(images, shapes, padding="max_detections", return_tensors="pt", location="cuda")
-        return gather_outputs(model.forward_padded())
+        pending.append(step_gather(nstep[0]))
+        nstep[0] += 1
+        return pending.pop(0).wait() if len(pending) > 1 else None
+
+    def drain():
+        out = None
+        while pending:
+            out = pending.pop(0).wait()
+        return out
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
+    drain()
     model.enable_kernel_timing(True)
     model.enable_stage_timing(True)
     model.kernel_timing(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
+        step()
+    out = drain()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,8 +234,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, a.proposals, a.detections, seed=0xF2C)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_pg:
         dist.destroy_process_group()
 
 

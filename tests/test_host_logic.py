@@ -106,7 +106,7 @@ def test_shard_indices_cover_everything():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from vltk_amd.parallel import gather_outputs, shard_indices, OUTPUT_KEYS
+from vltk_amd.parallel import gather_outputs, gather_outputs_async, shard_indices, OUTPUT_KEYS, OutputBlock, output_spec
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 r = dist.get_rank()
 lo, hi = shard_indices(8, r, 2)
@@ -122,6 +122,18 @@ assert out["roi_features"].shape == (8, D, F)
 assert out["preds_per_image"].tolist() == list(range(8))          # image order == rank order of contiguous shards
 assert out["roi_features"][:, 0, 0].tolist() == [float(i) for i in range(8)]
 assert out["obj_probs"][:, 0].tolist() == [0.0] * 4 + [1.0] * 4
+# the product form: the model's own flat output block goes out as is, two steps in flight (bench.py's pipeline)
+handles = []
+for step in range(2):
+    blk = OutputBlock(output_spec(B, D, F))
+    for k in OUTPUT_KEYS:
+        blk[k].copy_(pad[k] + step if pad[k].dtype != torch.long else pad[k] + step)
+    handles.append(gather_outputs_async(blk))
+for step, hnd in enumerate(handles):
+    o = hnd.wait()
+    assert o["preds_per_image"].tolist() == [i + step for i in range(8)]
+    assert o["roi_features"].shape == (8, D, F) and o["roi_features"][:, 2, 5].tolist() == [float(i + step) for i in range(8)]
+    assert o["obj_ids"][5].tolist() == [50 + step, 51 + step, 52 + step]
 dist.destroy_process_group()
 print("ok", r)
 """

@@ -20,6 +20,7 @@ import torch
 
 from . import _lib as L
 from .config import CONFIG_NAME, WEIGHTS_NAME, Config
+from .parallel import OutputBlock, output_spec
 
 
 class ROIOutputs:
@@ -239,15 +240,8 @@ class FRCNN:
         rp.min_detections, rp.max_detections = int(ro.min_detections), D
         F = self.config.RESNETS.RES2_OUT_CHANNELS * 8
         dev = self.device
-        bufs = OrderedDict(
-            obj_ids=torch.empty((N, D), dtype=torch.int64, device=dev),
-            obj_probs=torch.empty((N, D), dtype=torch.float32, device=dev),
-            attr_ids=torch.empty((N, D), dtype=torch.int64, device=dev),
-            attr_probs=torch.empty((N, D), dtype=torch.float32, device=dev),
-            boxes=torch.empty((N, D, 4), dtype=torch.float32, device=dev),
-            preds_per_image=torch.empty((N,), dtype=torch.int64, device=dev),
-            roi_features=torch.empty((N, D, F), dtype=torch.float32, device=dev),
-        )
+        # one flat block, the seven arrays are views (so the multi-GPU exchange is a single all-gather: parallel.py)
+        bufs = OutputBlock(output_spec(N, D, F), device=dev)
         out = L.vk_outputs(*[bufs[k].data_ptr() for k in bufs])
         stream = torch.cuda.current_stream(dev).cuda_stream
         L.call("vk_forward", self._h, images.data_ptr(), N, H, W, hw.ctypes.data_as(C.c_void_p),
