@@ -1,0 +1,156 @@
+"""Pipelined extraction loop (vltk_amd/pipeline.py): host logic with a stand-in model on the CPU (one rank and two gloo
+ranks), and -- on the GPU -- the pipeline's Arrow file against the same images pushed through the steps one by one."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_FAKE = r"""
+import numpy as np, torch
+from vltk_amd.parallel import OutputBlock, output_spec
+
+class RO:
+    max_detections = 3
+
+class FakeModel:
+    '''Deterministic stand-in: every output is a function of the image's first pixel (= its global index).'''
+    device = torch.device("cpu")
+    roi_outputs = RO()
+    F = 8
+    def __call__(self, images, sizes, scales_yx=None):
+        B = images.shape[0]
+        blk = OutputBlock(output_spec(B, 3, self.F))
+        v = images[:, 0, 0, 0]
+        blk["obj_ids"].copy_((v.view(B, 1) * 10 + torch.arange(3)).long())
+        blk["attr_ids"].copy_((v.view(B, 1) * 100 + torch.arange(3)).long())
+        blk["obj_probs"].fill_(0.5); blk["attr_probs"].fill_(0.25)
+        blk["boxes"].copy_((v.view(B, 1, 1) + torch.tensor([0.5, 1.5, 2.5, 3.49])).expand(B, 3, 4) * scales_yx[:, :1].view(B, 1, 1))
+        blk["preds_per_image"].fill_(3)
+        blk["roi_features"].copy_(v.view(B, 1, 1).expand(B, 3, self.F) + torch.arange(self.F) / 16)
+        self._blk = blk
+    def forward_padded(self):
+        return self._blk
+
+def fake_preprocess(raws, ids):
+    x = torch.stack([torch.as_tensor(r).float().permute(2, 0, 1) for r in raws])
+    n = x.shape[0]
+    return ids, x, torch.tensor([[4, 6]] * n), torch.full((n, 2), 2.0)
+
+def items(lo, hi):
+    return [(f"img{i}", np.full((4, 6, 3), i, dtype=np.uint8)) for i in range(lo, hi)]
+
+def check(path, n):
+    from vltk_amd.extraction import load_extraction
+    table, meta = load_extraction(path)
+    assert table.num_rows == n
+    rows = {r["imgid"]: r for r in table.to_pylist()}
+    assert sorted(rows) == sorted(f"img{i}" for i in range(n))
+    for i in range(n):
+        r = rows[f"img{i}"]
+        assert r["object_ids"] == [10.0 * i, 10.0 * i + 1, 10.0 * i + 2]
+        assert r["attr_ids"] == [100.0 * i, 100.0 * i + 1, 100.0 * i + 2]
+        # boxes (i + .5, 1.5, 2.5, 3.49) * 2 -> rounded half to even
+        assert r["box"][0] == [float(np.round(np.float32(2 * (i + d)))) for d in (0.5, 1.5, 2.5, 3.49)], r["box"][0]
+        assert r["features"][2] == [i + k / 16 for k in range(8)]
+        assert meta["img_to_row_map"][f"img{i}"] == [x["imgid"] for x in table.to_pylist()].index(f"img{i}")
+"""
+
+
+def test_pipeline_one_rank_ragged(tmp_path):
+    ns = {}
+    sys.path.insert(0, ROOT)
+    exec(_FAKE, ns)
+    from vltk_amd.pipeline import ExtractionPipeline
+    path = str(tmp_path / "vg" / "frcnn" / "train.arrow")
+    pipe = ExtractionPipeline(ns["FakeModel"](), ns["fake_preprocess"], path, batch_size=3, visual_dim=8, dataset="vg")
+    out = pipe.run(ns["items"](0, 7))
+    assert out == path and pipe.images_done == 7
+    ns["check"](path, 7)
+
+
+def test_pipeline_writer_error_surfaces(tmp_path):
+    ns = {}
+    sys.path.insert(0, ROOT)
+    exec(_FAKE, ns)
+    from vltk_amd.pipeline import ExtractionPipeline
+    pipe = ExtractionPipeline(ns["FakeModel"](), ns["fake_preprocess"], str(tmp_path / "t.arrow"), batch_size=2, visual_dim=8)
+    dup = ns["items"](0, 3) + ns["items"](1, 2) + ns["items"](3, 9)         # a duplicate imgid: the writer raises
+    with pytest.raises(ValueError, match="duplicate imgid"):
+        pipe.run(dup)
+
+
+_WORKER = _FAKE + r"""
+import os, sys, torch.distributed as dist
+from vltk_amd.parallel import shard_indices
+from vltk_amd.pipeline import ExtractionPipeline
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+r, N = dist.get_rank(), 11
+lo, hi = shard_indices(N, r, 2)
+path = sys.argv[4]
+pipe = ExtractionPipeline(FakeModel(), fake_preprocess, path, batch_size=2, visual_dim=8, dataset="vg")
+pipe.set_global_ids([f"img{i}" for i in range(N)])
+out = pipe.run(items(lo, hi), n_items=N)
+dist.barrier()
+if r == 0:
+    assert out == path
+    check(path, N)
+else:
+    assert out is None
+dist.destroy_process_group()
+print("ok", r)
+"""
+
+
+def test_pipeline_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text("import sys\nsys.path.insert(0, sys.argv[1])\n" + _WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(tmp_path / "train.arrow")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
+
+
+@pytest.mark.gpu
+def test_pipeline_matches_step_by_step_on_gpu(tmp_path):
+    """Raw uint8 images of three sizes -> pipeline (batch 4, ragged tail) vs the same steps called one batch at a time."""
+    from vltk_amd import FRCNN, make_state_dict
+    from vltk_amd.config import Config, vg_c4_config_dict
+    from vltk_amd.extraction import ExtractionWriter, load_extraction
+    from vltk_amd.pipeline import ExtractionPipeline
+    from vltk_amd.preprocess import Preprocess
+    d = vg_c4_config_dict(post_nms_topk=30, detections=12)
+    d["input"]["min_size_test"], d["input"]["max_size_test"] = 160, 256
+    cfg = Config(d)
+    model = FRCNN(cfg, precision="fp16").load_state_dict(make_state_dict(cfg, seed=1234)).eval()
+    pre = Preprocess(cfg)
+    g = np.random.Generator(np.random.PCG64(5))
+    shapes = [(120, 160), (96, 200), (150, 110)]
+    items = [(f"id{i}", g.integers(0, 256, shapes[i % 3] + (3,), dtype=np.uint8)) for i in range(10)]
+    p1 = str(tmp_path / "a" / "train.arrow")
+    pipe = ExtractionPipeline(model, pre, p1, batch_size=4, dataset="synthetic", model_config=cfg.to_dict())
+    assert pipe.run(items) == p1
+    # step by step, no threads, no pinned ring
+    p2 = str(tmp_path / "b" / "train.arrow")
+    with ExtractionWriter(p2, 12, 2048, dataset="synthetic", model_config=cfg.to_dict()) as w:
+        for k in range(0, 10, 4):
+            part = items[k:k + 4]
+            raws = [torch.from_numpy(r).cuda() for _, r in part]
+            while len(raws) < 4:
+                raws.append(raws[-1])
+            _, images, sizes, scales = pre(raws, list(range(4)))
+            model(images, sizes, scales_yx=scales)
+            blk = {kk: v.cpu().numpy() for kk, v in model.forward_padded().items()}
+            n = len(part)
+            w.write_batch([i for i, _ in part], blk["obj_ids"][:n].astype(np.float32), blk["attr_ids"][:n].astype(np.float32),
+                          np.round(blk["boxes"][:n]), blk["roi_features"][:n])
+    t1, m1 = load_extraction(p1)
+    t2, m2 = load_extraction(p2)
+    assert t1.num_rows == 10 and t1.equals(t2) and m1["img_to_row_map"] == m2["img_to_row_map"]
+    assert np.isfinite(np.asarray(t1.column("features")[0].as_py())).all()

@@ -76,6 +76,17 @@ class _Gathered:
     def __init__(self, block, flat_all, work, world):
         self.block, self.flat_all, self.work, self.world = block, flat_all, work, world
 
+    def wait_flat(self):
+        """(flat uint8 buffer, world): the gathered blocks back to back, rank by rank (the rank's own block when no
+        collective ran).  Each rank's slice parses with OutputBlock(spec, flat=slice)."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.flat_all is None:
+            blk = self.block if isinstance(self.block, OutputBlock) else OutputBlock.from_tensors(self.block)
+            return blk.flat, 1
+        return self.flat_all, self.world
+
     def wait(self):
         if self.work is not None:
             self.work.wait()
