@@ -168,6 +168,34 @@ def test_e2e_resnext_grouped_vs_oracle(precision, tol):
     stage_chain_check(m, out, oracle, shapes, tol=tol)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 1e-3)])
+@pytest.mark.parametrize("case", ["odd3", "single", "tiny"])
+def test_e2e_ragged_sizes_vs_oracle(case, precision, tol):
+    """Sizes that are no multiple of the stride (ceil-mode max-pool tails, partial GEMM tiles), three different content
+    sizes in one padded batch, a batch of one, and images so small that the RPN keeps fewer proposals than
+    POST_NMS_TOPK (ragged per-image counts): every stage against the oracle."""
+    cfg = vg_c4_config(depth=50, post_nms_topk=40, detections=10)
+    sd = make_state_dict(cfg, seed=31)
+    if case == "odd3":
+        H, W, shapes = 131, 203, [[131, 203], [97, 180], [120, 161]]
+    elif case == "single":
+        H, W, shapes = 117, 77, [[117, 77]]
+    else:
+        H, W, shapes = 48, 64, [[48, 64], [33, 40]]
+    x = synthetic_images(len(shapes), H, W, seed=11)
+    for i, (hh, ww) in enumerate(shapes):
+        x[i, :, hh:, :] = 0
+        x[i, :, :, ww:] = 0
+    m, out = run_gpu(cfg, sd, torch.from_numpy(x), shapes, precision)
+    oracle = FRCNNOracle(cfg, sd, emulate=None if precision == "fp32" else "fp16")
+    res4 = nchw(m.get_stage("res4"))
+    assert G.rel_err(res4, oracle.backbone(torch.from_numpy(x))) <= (1e-4 if precision == "fp32" else 5e-3)
+    stage_chain_check(m, out, oracle, shapes, tol=tol)
+    if case == "tiny":
+        counts = m.get_stage("proposal_counts").cpu().tolist()
+        assert min(counts) < 40, counts           # the ragged case really is ragged
+
+
 @pytest.mark.parametrize("tag", ["resnext50_8x8d", "r50_halve", "r50_halve_s3x3"])
 def test_e2e_config_variants_vs_reference_golden(golden_dir, tag):
     """Strict mode against the reference's own output for ResNeXt groups, RES5HALVE=true and stride in the 3x3."""
