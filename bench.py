@@ -151,17 +151,28 @@ def main():
         return gather_outputs_async(blk, out=gbuf.get(i % 3))
 
     nstep = [0]
+    inflight = []
 
-    def step():
-        # the all-gather of step i (one collective over the flat output block, RCCL's own stream) runs under the
-        # forward of step i+1; every gather is waited for inside the timed region (drain() before the closing barrier)
-        model(images, shapes, padding="max_detections", return_tensors="pt", location="cuda")
+    def finish(p):
+        # format like a blocking call would (padded "pt" tensors on the device), then start this step's all-gather: ONE
+        # collective over the flat output block on RCCL's own stream, which runs under the next step's kernels
+        p.wait(padding="max_detections", return_tensors="pt", location="cuda")
         pending.append(step_gather(nstep[0]))
         nstep[0] += 1
         return pending.pop(0).wait() if len(pending) > 1 else None
 
+    def step():
+        # vk_forward_begin of step i+1 is enqueued before step i is waited for, so the device never idles while the host
+        # formats a batch and launches the next one; every forward and every gather completes inside the timed region
+        # (drain() before the closing barrier)
+        inflight.append(model.forward_async(images, shapes))
+        if len(inflight) > 1:
+            finish(inflight.pop(0))
+
     def drain():
         out = None
+        while inflight:
+            finish(inflight.pop(0))
         while pending:
             out = pending.pop(0).wait()
         return out

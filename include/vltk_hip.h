@@ -136,6 +136,18 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W,
                const int32_t *image_hw, const float *scales_yx,
                const vk_roi_params *rp, const vk_outputs *out_dev, void *stream);
 
+/* The same forward in two halves, so that a caller can enqueue the next batch before the previous one has finished
+ * (the reference's loop is strictly serial, abc/extraction.py:189-213; on the GPU that leaves the device idle while the
+ * host formats one batch and launches the next).  vk_forward_begin enqueues everything on `stream` and returns a
+ * ticket; vk_forward_end(ticket) waits for that forward only, and raises the non-finite assertion (frcnn.py:148).
+ * Tickets must be ended in order; at most 4 may be open.  All forwards of a handle share its workspace: they must be
+ * enqueued on the same stream (they are stream-ordered, not concurrent); `image_hw` / `scales_yx` are consumed before
+ * _begin returns; the output buffers of different tickets must be distinct.  vk_forward == begin + end. */
+int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
+                     const int32_t *image_hw, const float *scales_yx,
+                     const vk_roi_params *rp, const vk_outputs *out_dev, void *stream, int64_t *ticket);
+int vk_forward_end(vk_handle *h, int64_t ticket);
+
 /* Intermediate tensors of the last forward, for stage-level parity tests.
  * name in {"res4","rpn_out","proposal_boxes","proposal_logits",
  * "proposal_counts","pooled","feature_pooled","obj_logits","attr_logits","chosen_deltas","keep_ids"};

@@ -272,6 +272,37 @@ def test_two_stream_head_is_bit_identical(setup):
             assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), (k, chunk)
 
 
+def test_forward_async_matches_sync(setup):
+    """vk_forward_begin / vk_forward_end: three different batches enqueued back to back and waited for in order give
+    bit-identical outputs to three blocking calls; tickets end in order; at most four may be open."""
+    cfg, sd, x, shapes = setup
+    m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
+    m.enable_kernel_timing(True)                 # the per-launch timers must cope with forwards still in flight
+    sh = torch.tensor(shapes)
+    xs = [x, x.flip(0) * 0.5, torch.cat([x, x])[:3] * 1.25]
+    shs = [sh, sh.flip(0), torch.cat([sh, sh])[:3]]
+    ref = []
+    for xi, si in zip(xs, shs):
+        m(xi, si)
+        ref.append({k: v.clone() for k, v in m.forward_padded().items()})
+    pend = [m.forward_async(xi.cuda(), si) for xi, si in zip(xs, shs)]
+    with pytest.raises(ValueError, match="not the oldest"):
+        pend[1].wait()
+    for p, r in zip(pend, ref):
+        blk = p.wait_raw()
+        for k in r:
+            assert torch.equal(blk[k], r[k]), k
+    kt = m.kernel_timing()
+    assert sum(v["launches"] for v in kt.values()) > 0
+    many = [m.forward_async(xs[0].cuda(), shs[0]) for _ in range(4)]
+    with pytest.raises(ValueError, match="already in flight"):
+        m.forward_async(xs[0].cuda(), shs[0])
+    for p in many:
+        blk = p.wait_raw()
+    for k in ref[0]:
+        assert torch.equal(blk[k], ref[0][k]), k
+
+
 def test_call_surface_like_reference_test(setup):
     """Counterpart of the reference's tests/frcnn_test.py:15-31 (call shape + mutable roi_outputs attributes)."""
     cfg, sd, x, shapes = setup

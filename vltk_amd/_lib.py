@@ -76,6 +76,9 @@ SIGNATURES = {
     "vk_num_weights": (_I, [_P, C.POINTER(_I)]),
     "vk_weight_name": (_I, [_P, _I, C.POINTER(C.c_char_p)]),
     "vk_forward": (_I, [_P, _P, _I, _I, _I, _P, _P, C.POINTER(vk_roi_params), C.POINTER(vk_outputs), _P]),
+    "vk_forward_begin": (_I, [_P, _P, _I, _I, _I, _P, _P, C.POINTER(vk_roi_params), C.POINTER(vk_outputs), _P,
+                              C.POINTER(C.c_int64)]),
+    "vk_forward_end": (_I, [_P, C.c_int64]),
     "vk_get_stage": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I)]),
     "vk_memcpy_d2d": (_I, [_P, _P, _SZ, _P]),
     "vk_enable_stage_timing": (_I, [_P, _I]),

@@ -24,18 +24,26 @@ namespace vk {
 thread_local KernelTimer *g_timer = nullptr;
 
 hipEvent_t KernelTimer::get() {
-    if (used == pool.size()) {
+    if (pool.empty()) {
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
-        pool.push_back(e);
+        all.push_back(e);
+        return e;
     }
-    return pool[used++];
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
 }
 void KernelTimer::collect() {
     const char *logp = getenv("VK_CONV_LOG");   // debug: one line per conv launch (shape, ms, TFLOP/s)
     FILE *lf = logp ? fopen(logp, "a") : nullptr;
+    std::vector<Rec> pending;       // launches of a forward that is still in flight (vk_forward_begin without its _end yet)
     for (auto &r : recs) {
         float t = 0.f;
+        if (hipEventQuery(r.e1) != hipSuccess) {
+            pending.push_back(r);
+            continue;
+        }
         if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
             if (lf) fprintf(lf, "%d %d %d %d %d %d %.5f %.1f\n", r.bucket, r.M, r.cout, r.cin, r.k, r.stride, t, r.flops / (t * 1e-3) / 1e12);
             launches[r.bucket] += 1;
@@ -43,13 +51,15 @@ void KernelTimer::collect() {
             flops[r.bucket] += r.flops;
             bytes[r.bucket] += r.bytes;
         }
+        pool.push_back(r.e0);
+        pool.push_back(r.e1);
     }
     if (lf) fclose(lf);
-    recs.clear();
-    used = 0;
+    recs.swap(pending);
+    (void)hipGetLastError();        // hipEventQuery's "not ready" must not show up in a later launch check
 }
 KernelTimer::~KernelTimer() {
-    for (auto e : pool) (void)hipEventDestroy(e);
+    for (auto e : all) (void)hipEventDestroy(e);
 }
 
 static thread_local char g_err[1024] = "";
@@ -133,6 +143,13 @@ struct vk_handle {
     hipStream_t side = nullptr;                     // second stream of the res4 stage (half-batch pipelining)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ev_valid = false;
+    // forwards in flight (vk_forward_begin .. vk_forward_end): ticket t uses slot t % VK_MAX_INFLIGHT
+    static constexpr int VK_MAX_INFLIGHT = 4;
+    int32_t *flag_host = nullptr;                   // pinned [VK_MAX_INFLIGHT]: the non-finite flag of each forward
+    char *meta_host = nullptr;                      // pinned [VK_MAX_INFLIGHT][meta_cap]: image_hw + scales_yx of each forward
+    size_t meta_cap = 0;
+    hipEvent_t ev_done[VK_MAX_INFLIGHT] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t next_ticket = 0, oldest_open = 0;       // tickets [oldest_open, next_ticket) have not been ended
 };
 
 namespace vk {
@@ -992,6 +1009,10 @@ int vk_destroy(vk_handle *h) {
     if (h->arena) (void)hipFree(h->arena);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->ev_done)
+        if (e) (void)hipEventDestroy(e);
+    if (h->flag_host) (void)hipHostFree(h->flag_host);
+    if (h->meta_host) (void)hipHostFree(h->meta_host);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -1036,7 +1057,16 @@ int vk_get_stage(vk_handle *h, const char *name, const void **dev_ptr, vk_dtype 
 
 int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const int32_t *image_hw,
                const float *scales_yx, const vk_roi_params *rp, const vk_outputs *out, void *stream) {
-    VK_REQUIRE(h && images_dev && image_hw && rp && out, VK_EINVAL, "forward: null argument");
+    int64_t ticket = -1;
+    VK_TRY(vk_forward_begin(h, images_dev, N, H, W, image_hw, scales_yx, rp, out, stream, &ticket));
+    return vk_forward_end(h, ticket);
+}
+
+int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W, const int32_t *image_hw,
+                     const float *scales_yx, const vk_roi_params *rp, const vk_outputs *out, void *stream, int64_t *ticket) {
+    VK_REQUIRE(h && images_dev && image_hw && rp && out && ticket, VK_EINVAL, "forward: null argument");
+    VK_REQUIRE(h->next_ticket - h->oldest_open < vk_handle::VK_MAX_INFLIGHT, VK_EINVAL,
+               "forward_begin: %d forwards are already in flight; end the oldest first", vk_handle::VK_MAX_INFLIGHT);
     VK_REQUIRE(h->finalized, VK_EINVAL, "forward: vk_finalize has not been called");
     VK_REQUIRE(N >= 1 && H >= 32 && W >= 32, VK_EINVAL, "forward: bad input size N=%d H=%d W=%d", N, H, W);
     VK_REQUIRE(rp->num_nms_thresh >= 1 && rp->num_nms_thresh <= VK_MAX_NMS_THRESH, VK_EINVAL, "forward: 1..%d nms thresholds", VK_MAX_NMS_THRESH);
@@ -1072,8 +1102,23 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
     const bool tm = h->timing;
     if (tm) VK_CHECK_HIP(hipEventRecord(h->ev[0], s));
 
-    VK_CHECK_HIP(hipMemcpyAsync(p.image_hw, image_hw, sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, s));
-    if (scales_yx) VK_CHECK_HIP(hipMemcpyAsync(p.scales, scales_yx, sizeof(float) * 2 * N, hipMemcpyHostToDevice, s));
+    // the caller's host arrays are copied into the ticket's pinned slot: consumed before this call returns, and the
+    // host-to-device copies are truly asynchronous
+    const size_t meta_need = (sizeof(int32_t) + sizeof(float)) * 2 * (size_t)N;
+    if (meta_need > h->meta_cap) {
+        VK_CHECK_HIP(hipDeviceSynchronize());
+        if (h->meta_host) VK_CHECK_HIP(hipHostFree(h->meta_host));
+        h->meta_host = nullptr;
+        h->meta_cap = align_up(meta_need, 4096);
+        VK_CHECK_HIP(hipHostMalloc((void **)&h->meta_host, h->meta_cap * vk_handle::VK_MAX_INFLIGHT, hipHostMallocDefault));
+    }
+    char *meta = h->meta_host + (size_t)(h->next_ticket % vk_handle::VK_MAX_INFLIGHT) * h->meta_cap;
+    memcpy(meta, image_hw, sizeof(int32_t) * 2 * N);
+    VK_CHECK_HIP(hipMemcpyAsync(p.image_hw, meta, sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, s));
+    if (scales_yx) {
+        memcpy(meta + sizeof(int32_t) * 2 * N, scales_yx, sizeof(float) * 2 * N);
+        VK_CHECK_HIP(hipMemcpyAsync(p.scales, meta + sizeof(int32_t) * 2 * N, sizeof(float) * 2 * N, hipMemcpyHostToDevice, s));
+    }
     VK_CHECK_HIP(hipMemsetAsync(p.nonfinite, 0, sizeof(int32_t), s));
 
     // ---- backbone (ResNet.forward frcnn.py:1076-1090) ----
@@ -1248,12 +1293,28 @@ int vk_forward(vk_handle *h, const float *images_dev, int N, int H, int W, const
         h->ev_valid = true;
     }
 
-    // the reference asserts finite boxes on the host (frcnn.py:148): one 4-byte read-back
-    int32_t flag = 0;
-    VK_CHECK_HIP(hipMemcpyAsync(&flag, p.nonfinite, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    VK_CHECK_HIP(hipStreamSynchronize(s));
+    // the reference asserts finite boxes on the host (frcnn.py:148): one 4-byte read-back into the ticket's pinned slot
+    if (!h->flag_host) {
+        VK_CHECK_HIP(hipHostMalloc((void **)&h->flag_host, sizeof(int32_t) * vk_handle::VK_MAX_INFLIGHT, hipHostMallocDefault));
+        for (auto &e : h->ev_done) VK_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int slot = (int)(h->next_ticket % vk_handle::VK_MAX_INFLIGHT);
+    VK_CHECK_HIP(hipMemcpyAsync(&h->flag_host[slot], p.nonfinite, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    VK_CHECK_HIP(hipEventRecord(h->ev_done[slot], s));
+    *ticket = h->next_ticket++;
+    return VK_OK;
+}
+
+int vk_forward_end(vk_handle *h, int64_t ticket) {
+    VK_REQUIRE(h, VK_EINVAL, "forward_end: null handle");
+    VK_REQUIRE(ticket == h->oldest_open && ticket < h->next_ticket, VK_EINVAL,
+               "forward_end: ticket %lld is not the oldest forward in flight (%lld)", (long long)ticket, (long long)h->oldest_open);
+    const int slot = (int)(ticket % vk_handle::VK_MAX_INFLIGHT);
+    h->oldest_open++;
+    VK_CHECK_HIP(hipSetDevice(h->device));
+    VK_CHECK_HIP(hipEventSynchronize(h->ev_done[slot]));
     if (h->ktimer) h->ktimer->collect();
-    VK_REQUIRE(flag == 0, VK_ENONFINITE, "Box tensor contains infinite or NaN!");
+    VK_REQUIRE(h->flag_host[slot] == 0, VK_ENONFINITE, "Box tensor contains infinite or NaN!");
     return VK_OK;
 }
 

@@ -96,14 +96,14 @@ struct KernelTimer {
         double bytes;
     };
     std::vector<Rec> recs;
-    std::vector<hipEvent_t> pool;
-    size_t used = 0;
+    std::vector<hipEvent_t> pool;   // free events
+    std::vector<hipEvent_t> all;    // every event ever created (destroyed with the timer)
     int64_t launches[VK_NUM_KERNEL_BUCKETS] = {};
     double ms[VK_NUM_KERNEL_BUCKETS] = {};
     double flops[VK_NUM_KERNEL_BUCKETS] = {};
     double bytes[VK_NUM_KERNEL_BUCKETS] = {};   // algorithmic: input + output (+ residual) + weights, once each
     hipEvent_t get();
-    void collect();   // after the stream has been synchronised
+    void collect();   // accumulates every launch whose end event has completed; the rest stay pending
     ~KernelTimer();
 };
 extern thread_local KernelTimer *g_timer;

@@ -70,6 +70,39 @@ def _c_config(cfg, precision):
 _TORCH_DT = {L.VK_F32: torch.float32, L.VK_F16: torch.float16, L.VK_I64: torch.int64, L.VK_I32: torch.int32}
 
 
+class PendingForward:
+    """A forward in flight (FRCNN.forward_async)."""
+
+    def __init__(self, model, ticket, block, hw, images):
+        self.model, self.ticket, self.block, self.hw = model, ticket, block, hw
+        self._images = images          # keeps the input alive until the kernels have read it
+        self._done = False
+
+    def wait_raw(self):
+        """Finish the forward; returns the fixed-capacity OutputBlock ([N, D, ...] device tensors)."""
+        if not self._done:
+            try:
+                L.call("vk_forward_end", self.model._h, C.c_int64(self.ticket))
+            except ValueError:          # out of order: the ticket is still open
+                raise
+            except Exception:           # the forward finished and failed (non-finite boxes, frcnn.py:148)
+                self._done, self._images = True, None
+                raise
+            self._done, self._images = True, None
+            self.model._last_padded = self.block
+        return self.block
+
+    def wait(self, **kwargs):
+        return FRCNN._format(self.wait_raw(), self.hw, **kwargs)
+
+    def __del__(self):                 # a dropped handle must not leave its ticket open
+        try:
+            if not self._done and self.model._h:
+                self.wait_raw()
+        except Exception:
+            pass
+
+
 class FRCNN:
     def __init__(self, cfg, precision=None, device=None):
         if not torch.cuda.is_available():
@@ -211,6 +244,12 @@ class FRCNN:
     def forward(self, images, image_shapes, gt_boxes=None, proposals=None, scales_yx=None, ignorey=None, **kwargs):
         """kwargs (v1.0.0 semantics): max_detections, return_tensors {"np","pt",None},
         padding {None,"max_detections","max_batch"}, pad_value, location {"cuda","cpu"}."""
+        return self.forward_async(images, image_shapes, gt_boxes, proposals, scales_yx, ignorey).wait(**kwargs)
+
+    def forward_async(self, images, image_shapes, gt_boxes=None, proposals=None, scales_yx=None, ignorey=None):
+        """Enqueue a forward and return at once (vk_forward_begin); `.wait(**kwargs)` on the returned handle finishes it
+        (vk_forward_end) and formats the outputs like forward().  Up to four may be in flight; they must be waited for
+        in order, on the same stream.  The caller must not modify `images` before wait() returns."""
         if self.training:
             raise NotImplementedError()            # frcnn.py:1930-1931
         if proposals is not None:
@@ -244,11 +283,11 @@ class FRCNN:
         bufs = OutputBlock(output_spec(N, D, F), device=dev)
         out = L.vk_outputs(*[bufs[k].data_ptr() for k in bufs])
         stream = torch.cuda.current_stream(dev).cuda_stream
-        L.call("vk_forward", self._h, images.data_ptr(), N, H, W, hw.ctypes.data_as(C.c_void_p),
+        ticket = C.c_int64(-1)
+        L.call("vk_forward_begin", self._h, images.data_ptr(), N, H, W, hw.ctypes.data_as(C.c_void_p),
                sc.ctypes.data_as(C.c_void_p) if sc is not None else None, C.byref(rp), C.byref(out),
-               C.c_void_p(stream))
-        self._last_padded = bufs
-        return self._format(bufs, hw, **kwargs)
+               C.c_void_p(stream), C.byref(ticket))
+        return PendingForward(self, ticket.value, bufs, hw, images)
 
     inference = forward
 

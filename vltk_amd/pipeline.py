@@ -136,44 +136,68 @@ class ExtractionPipeline:
             wthread.start()
         if self.world > 1:
             gbuf = [torch.empty(self.world * nbytes, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
-        copy_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        on_gpu = dev.type == "cuda"
+        copy_stream = torch.cuda.Stream(device=dev) if on_gpu else None
+        upload_stream = torch.cuda.Stream(device=dev) if on_gpu else None
+
+        def finish(p, ids, n_valid, step):
+            blk = p.wait_raw()
+            slot = step % self.depth
+            if self.rank == 0:
+                # back-pressure: at most `depth` batches in flight; slot s owns pinned buffer s AND gather buffer s, so
+                # a gather never lands in a buffer whose device-to-host copy is still running
+                slot = free.get()
+                if self._writer_error is not None:
+                    raise self._writer_error
+            handle = gather_outputs_async(blk, self.group, out=gbuf[slot] if gbuf else None)
+            flat, _ = handle.wait_flat()
+            if self.rank == 0:
+                if copy_stream is not None:
+                    copy_stream.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(copy_stream):
+                        host[slot].copy_(flat, non_blocking=True)
+                        flat.record_stream(copy_stream)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                else:
+                    host[slot].copy_(flat)
+                    ev = _DoneEvent()
+                # which ids each rank's block holds in this step (all ranks derive it from the spans alone)
+                ids_per_rank = []
+                for r, (lo, hi) in enumerate(spans):
+                    a, b = min(lo + step * self.B, hi), min(lo + (step + 1) * self.B, hi)
+                    ids_per_rank.append(ids[:n_valid] if r == self.rank else self._ids_of(r, a, b))
+                write_q.put((slot, host[slot], ev, ids_per_rank))
+            self.images_done += n_valid
+
         try:
+            prev = None
             for step in range(n_steps):
                 job = load_q.get()
                 if isinstance(job, BaseException):
                     raise job
                 ids, raws, n_valid = job
-                dev_raws = [torch.from_numpy(r).to(dev) for r in raws]          # uint8 stays uint8 over PCIe
+                # uint8 stays uint8 over PCIe; the copies run on their own stream (a pageable host-to-device copy on the
+                # compute stream would make the host wait for the forward that is still running there)
+                if on_gpu:
+                    with torch.cuda.stream(upload_stream):
+                        dev_raws = [torch.from_numpy(r).to(dev) for r in raws]
+                    torch.cuda.current_stream(dev).wait_stream(upload_stream)
+                    for t in dev_raws:
+                        t.record_stream(torch.cuda.current_stream(dev))
+                else:
+                    dev_raws = [torch.from_numpy(r) for r in raws]
                 _, images, sizes, scales_yx = self.preprocess(dev_raws, list(range(self.B)))
-                self.model(images, sizes, scales_yx=scales_yx)
-                blk = self.model.forward_padded()
-                slot = step % self.depth
-                if self.rank == 0:
-                    # back-pressure: at most `depth` batches in flight; slot s owns pinned buffer s AND gather buffer s, so
-                    # a gather never lands in a buffer whose device-to-host copy is still running
-                    slot = free.get()
-                    if self._writer_error is not None:
-                        raise self._writer_error
-                handle = gather_outputs_async(blk, self.group, out=gbuf[slot] if gbuf else None)
-                flat, _ = handle.wait_flat()
-                if self.rank == 0:
-                    if copy_stream is not None:
-                        copy_stream.wait_stream(torch.cuda.current_stream(dev))
-                        with torch.cuda.stream(copy_stream):
-                            host[slot].copy_(flat, non_blocking=True)
-                            flat.record_stream(copy_stream)
-                            ev = torch.cuda.Event()
-                            ev.record(copy_stream)
-                    else:
-                        host[slot].copy_(flat)
-                        ev = _DoneEvent()
-                    # which ids each rank's block holds in this step (all ranks derive it from the spans alone)
-                    ids_per_rank = []
-                    for r, (lo, hi) in enumerate(spans):
-                        a, b = min(lo + step * self.B, hi), min(lo + (step + 1) * self.B, hi)
-                        ids_per_rank.append(ids[:n_valid] if r == self.rank else self._ids_of(r, a, b))
-                    write_q.put((slot, host[slot], ev, ids_per_rank))
-                self.images_done += n_valid
+                if hasattr(self.model, "forward_async"):      # enqueue this batch behind the previous one, then finish that one
+                    p = self.model.forward_async(images, sizes, scales_yx=scales_yx)
+                else:
+                    self.model(images, sizes, scales_yx=scales_yx)
+                    p = _Finished(self.model.forward_padded())
+                if prev is not None:
+                    finish(*prev)
+                prev = (p, ids, n_valid, step)
+            if prev is not None:
+                finish(*prev)
         finally:
             if wthread is not None:
                 write_q.put(_STOP)
@@ -198,6 +222,16 @@ class ExtractionPipeline:
 class _DoneEvent:
     def synchronize(self):
         pass
+
+
+class _Finished:
+    """A forward that has already completed (models without forward_async)."""
+
+    def __init__(self, block):
+        self.block = block
+
+    def wait_raw(self):
+        return self.block
 
 
 def extract_images(model, preprocess, items, savedir, split="train", dataset=None, batch_size=32, processor_args=None,
