@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end evidence, run ON THE GPU BOX from the repo root (gpurun): the bench line, the rocprofv3 kernel-trace
+# summary of the same command, and the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, --kernel-trace only).
+# usage: bash tools/refresh_profiles.sh <tag>      -> gpurun_out/<tag>_*
+set -e
+TAG=${1:-l}
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py --steps 8 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "bench done"
+rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
+echo "kernel trace done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc/f -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pmc_f.log 2>&1
+echo "pmc fetch done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc/w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pmc_w.log 2>&1
+echo "pmc write done"
+find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_traffic.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
+# keep only the summaries (the raw traces are large)
+rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc
+tail -3 $OUT/${TAG}_pmc_summary.txt
