@@ -34,20 +34,57 @@ def _regs(tok):
 
 
 def scan_function(lines):
-    """lines: the instructions of one kernel.  Returns [(line_no, text, pending_read_line)]."""
+    """lines: the instructions of one kernel.  Returns [(line_no, text, pending_read_line)].
+
+    The scan follows the text top to bottom and carries the queues of pending reads along FORWARD branches: the state at
+    an `s_branch` / `s_cbranch_*` is saved for its target label and merged in when the label is reached; after an
+    unconditional branch the fall-through text is unreachable, so it starts from what its own predecessors saved (hipcc lays
+    out a loop's exit block before the loop body, so a purely linear scan would see the exit block's loads as pending inside
+    the loop).  Backward branches (loop back-edges) are covered by the kernels' rule that every back-edge follows a
+    `s_waitcnt lgkmcnt(0)`: the state saved at a back-edge for an already-passed label must be empty, and is checked."""
     pend, vpend, found = [], [], []          # in-flight LDS reads / in-flight global loads into registers (not LDS-DMA)
+    saved = {}                               # label -> (pend, vpend) carried by forward branches
+    passed = set()
+    reachable = True
     in_asm = False                           # only HAND-ISSUED loads are tracked: hipcc waits correctly for its own
+
+    def merge(a, b):
+        return sorted(set((i, frozenset(r)) for i, r in a) | set((i, frozenset(r)) for i, r in b))
+
     for i, raw in enumerate(lines):
         if "#ASMSTART" in raw:
             in_asm = True
         elif "#ASMEND" in raw:
             in_asm = False
         t = raw.split(";")[0].strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            lab = m.group(1)
+            sp, sv = saved.pop(lab, ([], []))
+            if reachable:
+                pend, vpend = merge(pend, sp), merge(vpend, sv)
+            else:
+                pend, vpend = merge([], sp), merge([], sv)
+            reachable = True
+            passed.add(lab)
+            continue
         if not t or t.endswith(":") or t.startswith("."):
             continue
         parts = t.split(None, 1)
         op, args = parts[0], (parts[1] if len(parts) > 1 else "")
         ops = [a.strip() for a in args.split(",")]
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            lab = ops[0]
+            if lab in passed:                 # back-edge: nothing may be in flight (see the docstring)
+                for li, rs in list(pend) + list(vpend):
+                    found.append((i, t + "   [back-edge with a read in flight]", li))
+            else:
+                sp, sv = saved.get(lab, ([], []))
+                saved[lab] = (merge(sp, pend), merge(sv, vpend))
+            if op == "s_branch":
+                reachable = False
+                pend, vpend = [], []
+            continue
         if op.startswith("ds_read"):
             if in_asm:
                 pend.append((i, set(_regs(ops[0]))))
@@ -77,8 +114,8 @@ def scan_function(lines):
         used = set()
         for a in ops:
             used |= set(_regs(a))
-        for li, rs in pend + vpend:
-            if used & rs:
+        for li, rs in list(pend) + list(vpend):
+            if used & set(rs):
                 found.append((i, t, li))
     return found
 
