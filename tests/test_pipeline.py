@@ -154,3 +154,60 @@ def test_pipeline_matches_step_by_step_on_gpu(tmp_path):
     t2, m2 = load_extraction(p2)
     assert t1.num_rows == 10 and t1.equals(t2) and m1["img_to_row_map"] == m2["img_to_row_map"]
     assert np.isfinite(np.asarray(t1.column("features")[0].as_py())).all()
+
+
+_GPU_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from vltk_amd import FRCNN, make_state_dict
+from vltk_amd.config import Config, vg_c4_config_dict
+from vltk_amd.parallel import shard_indices
+from vltk_amd.pipeline import ExtractionPipeline
+from vltk_amd.preprocess import Preprocess
+rank, world, port, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+d = vg_c4_config_dict(post_nms_topk=30, detections=12)
+d["input"]["min_size_test"], d["input"]["max_size_test"] = 160, 256
+cfg = Config(d)
+model = FRCNN(cfg, precision="fp16").load_state_dict(make_state_dict(cfg, seed=1234)).eval()
+g = np.random.Generator(np.random.PCG64(5))
+shapes = [(120, 160), (96, 200), (150, 110)]
+N = 11
+items = [(f"id{i}", g.integers(0, 256, shapes[i % 3] + (3,), dtype=np.uint8)) for i in range(N)]
+lo, hi = shard_indices(N, rank, world)
+pipe = ExtractionPipeline(model, Preprocess(cfg), out, batch_size=3, dataset="synthetic")
+pipe.set_global_ids([i for i, _ in items])
+pipe.run(items[lo:hi], n_items=N)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+@pytest.mark.gpu
+def test_pipeline_two_ranks_on_one_gpu_match_one_rank(tmp_path):
+    """The real model under the multi-rank loop: two processes share the GPU (gloo carries the flat output block between
+    them; RCCL needs one GPU per rank), rank 0's Arrow file holds the same rows as a one-rank run of the same images.
+    An image's outputs do not depend on what else is in its batch, so the different batch composition must not matter."""
+    from vltk_amd.extraction import load_extraction
+    script = tmp_path / "w.py"
+    script.write_text(_GPU_WORKER)
+    port = str(33500 + os.getpid() % 2000)
+    one = subprocess.run([sys.executable, str(script), ROOT, "0", "1", port, str(tmp_path / "one.arrow")],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port, str(tmp_path / "two.arrow")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    t1, m1 = load_extraction(str(tmp_path / "one.arrow"))
+    t2, m2 = load_extraction(str(tmp_path / "two.arrow"))
+    assert t1.num_rows == t2.num_rows == 11
+    r1 = {r["imgid"]: r for r in t1.to_pylist()}
+    r2 = {r["imgid"]: r for r in t2.to_pylist()}
+    assert sorted(r1) == sorted(r2)
+    for k in r1:
+        assert r1[k] == r2[k], k
