@@ -120,6 +120,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # validation only (one-GPU box): VLTK_AMD_BENCH_ONE_GPU=1 puts every rank on device 0 and uses gloo for the exchange
+    # (RCCL needs one GPU per rank), so that the N > 1 control flow of this file can be run where only one GPU exists
+    one_gpu = os.environ.get("VLTK_AMD_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_pg = world > 1 or os.environ.get("VLTK_AMD_FORCE_COLLECTIVE") == "1"     # the latter: one-rank RCCL group (validation)
     if use_pg:
@@ -127,7 +132,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
     from vltk_amd.parallel import gather_outputs_async
