@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of FRCNN feature extraction (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Called plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the process starts the N ranks itself, as children
+of a parent that never touches HIP, and relays rank 0's JSON line and the job's return code.
 
 A step = one vk_forward over one per-GPU batch of synthetic 800x1333 images already resident in HBM
 (ResNet-101-C4 fp16, R = 300 RPN proposals through the Res5 head, up to 100 detections per image),
@@ -56,40 +59,107 @@ def stage_fractions(st, B, R, arch):
     return out
 
 
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(batch, proposals, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent or for another workload/kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if d.get("batch") == batch and d.get("proposals") == proposals and d.get("kernel") == kernel:
-            return d["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    """(HBM bytes per launch of the dominant kernel, source) from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950; tools/refresh_profiles.sh writes the file).  PMC counters cannot be read from inside the process, so the
+    figure is NOT measured in this run: the source file is named next to it.  (None, None) if no file matches."""
+    for fn in PMC_TRAFFIC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except Exception:
+            continue
+        for e in (d.get("kernels") or [d]):
+            if e.get("batch", d.get("batch")) == batch and e.get("proposals", d.get("proposals")) == proposals \
+                    and e.get("kernel") == kernel:
+                return e["hbm_bytes_per_launch"], "profiles/" + fn
+    return None, None
 
 
-def cpu_baseline(cfg, sd, R, det, seed):
-    """The oracle (CPU restatement of the reference path, torch CPU ops, all host cores) on ONE image."""
+def cpu_baseline(cfg, sd, R, det, seed, n_images=4, repeats=3):
+    """The oracle (CPU restatement of the reference path, torch CPU ops) on a batch of N=4 images, median of 3 runs
+    (SURVEY.md 8d).  Threads = the cores this process may use, capped at the one-GPU box's CPU share of 16 (the box shows
+    every core of the host; oversubscribing them was measured 10x slower) -- VLTK_AMD_CPU_THREADS overrides."""
+    import statistics
     import torch
     from oracle.frcnn_oracle import FRCNNOracle
     from vltk_amd import synthetic_images
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)      # the 1-GPU box's CPU share (oversubscribing 256 visible cores is 10x slower)
+    cores = int(os.environ.get("VLTK_AMD_CPU_THREADS", min(visible, 16)))
     torch.set_num_threads(cores)
     o = FRCNNOracle(cfg, sd)
-    x = torch.from_numpy(synthetic_images(1, 800, 1333, seed=seed))
-    t0 = time.time()
-    out = o.forward(x, [[800, 1333]])
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image 800x1333, R={R}, D={det}, fp32, oracle/frcnn_oracle.py, {dt:.1f} s, "
-                      f"{int(out['preds_per_image'][0])} detections"}
+    x = torch.from_numpy(synthetic_images(n_images, 800, 1333, seed=seed))
+    shapes = [[800, 1333]] * n_images
+    times = []
+    for _ in range(repeats):
+        t0 = time.time()
+        out = o.forward(x, shapes)
+        times.append(time.time() - t0)
+    dt = statistics.median(times)
+    return {"value": round(n_images / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_images} images 800x1333 in one batch, R={R}, D={det}, fp32, oracle/frcnn_oracle.py, median of "
+                      f"{repeats} runs ({', '.join('%.1f' % t for t in times)} s), {cores} threads of {visible} visible cores, "
+                      f"{[int(v) for v in out['preds_per_image']]} detections"}
+
+
+def selftest_launch(a):
+    """What every rank does under --selftest-launch: join a gloo group, take part in one all-reduce, rank 0 prints one
+    JSON line.  Exercises launch_ranks() (children, relayed line, return code) where no GPU exists."""
+    import torch
+    import torch.distributed as dist
+    json_fd = os.dup(1)             # as main(): stdout carries the ONE JSON line, everything else goes to stderr
+    os.dup2(2, 1)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+    print("noise on stdout from rank", rank, flush=True)           # must not reach the caller's stdout as a JSON line
+    if a.selftest_launch == "fail" and rank == world - 1:
+        return 3
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "selftest", "n_gpus": world, "n_ranks_seen": int(t.item())}) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def launch_ranks(a):
+    """--gpus N > 1 without a launcher: start the N ranks as children (torch.distributed.run) from this process, which
+    has not imported torch or touched HIP, relay rank 0's one JSON line on stdout and return the job's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:
+        txt = raw.decode(errors="replace").rstrip("\n")
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:                       # a rank failed: no number is reported for the job
+        return rc
+    if line is None:
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -104,7 +174,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--arch", default="r101", choices=["r101", "x152"],
                     help="r101 = the BASELINE workload (configs[1]); x152 = ResNeXt-152 32x8d (SURVEY.md 8d config c4, extra)")
+    ap.add_argument("--selftest-launch", default=None, choices=["ok", "fail"],
+                    help="CPU check of the rank launcher only: gloo ranks, no GPU, no model (tests/test_bench_launcher.py)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    if a.selftest_launch:
+        sys.exit(selftest_launch(a))
 
     # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  With RCCL's streams alive, the forward's second
     # stream (res3/res4 half-batches) lands on the main stream's queue and the halves serialise: measured 374 instead of
@@ -193,9 +269,7 @@ def main():
     for _ in range(a.warmup):
         step()
     drain()
-    model.enable_kernel_timing(True)
-    model.enable_stage_timing(True)
-    model.kernel_timing(reset=True)
+    # headline pass: EXACTLY a.steps steps, no per-launch timers, no stage events
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -203,10 +277,23 @@ def main():
     out = drain()
     barrier()
     dt = time.perf_counter() - t0
+    # breakdown pass (outside the headline): the same steps again with a HIP event pair around every conv launch and
+    # every stage; its own wall time is reported as ms_per_step_with_timers
+    model.enable_kernel_timing(True)
+    model.enable_stage_timing(True)
+    model.kernel_timing(reset=True)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    drain()
+    barrier()
+    dt_timers = time.perf_counter() - t1
+    n_ranks_seen = dist.get_world_size() if use_pg else 1
     if use_pg:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt, dt_timers], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_timers = float(t[0].item()), float(t[1].item())
     kt = model.kernel_timing()
     st = model.stage_timing_ms()                 # HIP events of the LAST step's stages (backbone / RPN head / proposals / RoI heads / outputs)
     assert out["roi_features"].shape[0] == world * B
@@ -219,12 +306,15 @@ def main():
         dom = kt[dom_key]
         dom_name, dom_desc = KERNEL_NAMES[dom_key]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(B, a.proposals, dom_name)
         all_ms = sum(v["ms"] for v in kt.values())
         all_fl = sum(v["flops"] for v in kt.values())
         line = {
             "metric": "images/sec FRCNN feature extraction, 800x1333 batch",
             "value": round(world * B * a.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "ms_per_step_with_timers": round(dt_timers / a.steps * 1e3, 3), "n_ranks_seen": n_ranks_seen,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("configs[1]: ResNet-101-C4 fp16" if a.arch == "r101" else "EXTRA (SURVEY.md 8d c4): ResNeXt-152 32x8d C4 fp16") +
                                    " (the reference has no FPN: SURVEY.md D1), "
@@ -232,7 +322,7 @@ def main():
                                    f"through the Res5 head, max {a.detections} detections/img, seeded synthetic weights",
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": pmc_traffic(B, a.proposals, dom_name),
+                         "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
@@ -249,7 +339,9 @@ def main():
                          "stages_last_step": stage_fractions(st, B, a.proposals, a.arch),
                          "all_conv_kernels_that_ran_alone": {"ms_per_step": round(all_ms / a.steps, 3),
                                               "tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms else 0.0,
-                                              "share_of_step": round(all_ms / (dt * 1e3), 4)}},
+                                              "share_of_step": round(all_ms / (dt_timers * 1e3), 4)},
+                         "note": "per-kernel and per-stage figures are from the breakdown pass (timers on), value / ms_per_step "
+                                 "from the headline pass (timers off)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, a.proposals, a.detections, seed=0xF2C)

@@ -55,11 +55,16 @@ def test_duplicate_and_shape_errors(tmp_path):
     w = ExtractionWriter(str(tmp_path / "x.arrow"), 4, 8)
     z = np.zeros
     w.write_batch(["a"], z((1, 4)), z((1, 4)), z((1, 4, 4)), z((1, 4, 8)))
-    with pytest.raises(ValueError, match="duplicate"):
-        w.write_batch(["a"], z((1, 4)), z((1, 4)), z((1, 4, 4)), z((1, 4, 8)))
+    # a repeated imgid is skipped (the reference prints the same message, extraction.py:183-185), also inside one batch
+    w.write_batch(["a"], z((1, 4)), z((1, 4)), z((1, 4, 4)), z((1, 4, 8)))
+    w.write_batch(["b", "a", "b", "c"], np.arange(16.0).reshape(4, 4), z((4, 4)), z((4, 4, 4)), z((4, 4, 8)))
+    assert w.rows == 3 and w.img_to_row == {"a": 0, "b": 1, "c": 2}
     with pytest.raises(ValueError, match="features must be"):
         w.write_batch(["b"], z((1, 4)), z((1, 4)), z((1, 4, 4)), z((1, 5, 8)))
-    w.close()
+    path = w.close()
+    table, meta = load_extraction(path)
+    assert table.num_rows == 3 and meta["img_to_row_map"] == {"a": 0, "b": 1, "c": 2}
+    assert table.column("object_ids").to_pylist()[2] == [12.0, 13.0, 14.0, 15.0]      # row "c" = row 3 of that batch
 
 
 @pytest.mark.skipif(not os.path.exists(FIXTURE), reason="reference fixture only exists in the build container")

@@ -6,8 +6,8 @@ upstream tensors on the oracle side, so a 1e-6 difference in a logit cannot masq
 index error; the free-running comparison is made as well and is margin-aware.
 
 Tolerances: fp32 strict mode 1e-3 (north_star) against the fp32 reference -- measured ~1e-5;
-fp16 fast mode 1e-3 against the fp16-emulating oracle stage by stage, and reported against
-the fp32 reference (bound 3e-2 on RoI features: fp16 storage through ~100 layers).
+fp16 fast mode (the benched one) 1e-3 against the fp32 reference on the outputs (RoI features,
+probabilities, boxes; identical detections), and 1e-3 stage by stage against the fp16-emulating oracle.
 """
 import os
 
@@ -138,17 +138,25 @@ def test_e2e_fp16_fast_vs_emulating_oracle(setup, golden):
     print(f"\n[fp16 vs fp16-emulating oracle, free-running backbone] res4 rel err {e:.3e}")
     assert e <= 5e-3
     stage_chain_check(m, out, oracle, shapes, tol=1e-3)
-    # reported: deviation of the fp16 pipeline from the fp32 reference
-    dev = G.rel_err(res4, golden["res4"])
-    print(f"\n[fp16 vs fp32 reference] res4 rel err {dev:.3e}")
-    assert dev <= 3e-2
-    ids_same = all(out["obj_ids"][i].cpu().tolist() == golden[f"obj_ids_{i}"].tolist() for i in range(len(shapes)))
-    print(f"[fp16 vs fp32 reference] detections identical: {ids_same}; min class margin in fixture {golden['cls_margin'].min():.2e}")
-    if ids_same:
-        for i in range(len(shapes)):
-            e = G.rel_err(out["roi_features"][i].cpu(), golden[f"roi_features_{i}"])
-            print(f"[fp16 vs fp32 reference] image {i} roi_features rel err {e:.3e}")
-            assert e <= 3e-2
+    fp16_vs_reference_golden(m, out, golden, len(shapes))
+
+
+def fp16_vs_reference_golden(m, out, golden, n):
+    """The benched (fp16) mode held to north_star's 1e-3 against the fp32 REFERENCE golden: identical detections, RoI
+    features, class / attribute probabilities and boxes <= 1e-3; res4 (an intermediate 100 fp16-storage layers deep,
+    measured 1.8e-3) is reported and bounded at 5e-3."""
+    dev = G.rel_err(nchw(m.get_stage("res4")), golden["res4"])
+    print(f"\n[fp16 vs fp32 reference] res4 rel err {dev:.3e} (reported; intermediate map)")
+    assert dev <= 5e-3
+    print(f"[fp16 vs fp32 reference] min class margin in fixture {golden['cls_margin'].min():.2e}")
+    np.testing.assert_array_equal(out["preds_per_image"].numpy(), golden["preds_per_image"])
+    for i in range(n):
+        np.testing.assert_array_equal(out["obj_ids"][i].cpu().numpy(), golden[f"obj_ids_{i}"])
+        np.testing.assert_array_equal(out["attr_ids"][i].cpu().numpy(), golden[f"attr_ids_{i}"])
+        for k in ("roi_features", "obj_probs", "attr_probs", "boxes"):
+            e = G.rel_err(out[k][i].cpu(), golden[f"{k}_{i}"])
+            print(f"[fp16 vs fp32 reference] image {i} {k} rel err {e:.3e}")
+            assert e <= 1e-3, (k, i, e)
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 1e-3)])
@@ -196,11 +204,12 @@ def test_e2e_ragged_sizes_vs_oracle(case, precision, tol):
         assert min(counts) < 40, counts           # the ragged case really is ragged
 
 
-@pytest.mark.parametrize("tag", ["resnext50_8x8d", "r50_halve", "r50_halve_s3x3"])
+@pytest.mark.parametrize("tag", ["resnext50_8x8d", "r50_halve", "r50_halve_s3x3", "resnext152_32x8d"])
 def test_e2e_config_variants_vs_reference_golden(golden_dir, tag):
-    """Strict mode against the reference's own output for ResNeXt groups, RES5HALVE=true and stride in the 3x3."""
+    """Strict mode against the reference's own output for ResNeXt groups, RES5HALVE=true, stride in the 3x3, and
+    ResNeXt-152 32x8d at its real depth and group count (BASELINE configs[3])."""
     from test_oracle_golden import variant_inputs
-    g = np.load(os.path.join(golden_dir, "e2e_variants.npz"))
+    g = np.load(os.path.join(golden_dir, "e2e_x152.npz" if tag == "resnext152_32x8d" else "e2e_variants.npz"))
     cfg, sd, x, shapes = variant_inputs(g, tag)
     m, out = run_gpu(cfg, sd, x, shapes, "fp32")
     res4 = nchw(m.get_stage("res4"))

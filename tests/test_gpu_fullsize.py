@@ -1,0 +1,131 @@
+"""-m gpu: BASELINE-size parity.
+
+(a) configs[1] as bench.py runs it -- 32 synthetic 800x1333 images, ResNet-101-C4 fp16, R = 300, D = 100 -- checked
+    through size-independent properties, against an N = 2 run of its first two images (bitwise) and one-stream against
+    two-stream backbone (bitwise) at real size;
+(b) ONE full-size image against the oracle: strict fp32 stage chain + free-running (1e-3), and the fp16 fast mode stage
+    by stage against the fp16-emulating oracle (1e-3), with its deviation from the fp32 oracle reported.
+The oracle needs ~5-10 s per full-size image and pass on the box's 16 host cores.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.frcnn_oracle import FRCNNOracle            # noqa: E402
+from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config   # noqa: E402
+
+import gpu_util as G                                   # noqa: E402
+from test_gpu_e2e import nchw, stage_chain_check       # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def bench_model():
+    cfg = vg_c4_config(post_nms_topk=300, detections=100)
+    sd = make_state_dict(cfg, seed=1234)
+    return cfg, sd, FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
+
+
+def test_configs1_batch32_fp16(bench_model):
+    cfg, sd, m = bench_model
+    B = 32
+    x = torch.from_numpy(synthetic_images(B, 800, 1333, seed=0xF2C)).cuda()
+    shapes = torch.tensor([[800, 1333]] * B)
+    out = m(x, shapes)
+    full = {k: v.clone() for k, v in m.forward_padded().items()}
+    res4 = m.get_stage("res4")
+    assert res4.shape == (B, 50, 84, 1024) and res4.dtype == torch.float16 and torch.isfinite(res4).all()
+    assert m.get_stage("proposal_counts").cpu().tolist() == [300] * B
+    ppi = out["preds_per_image"].tolist()
+    assert all(1 <= p <= 100 for p in ppi), ppi
+    for i in range(B):
+        f, b, p = out["roi_features"][i], out["boxes"][i], out["obj_probs"][i]
+        assert f.shape == (ppi[i], 2048) and torch.isfinite(f).all() and (f >= 0).all() and f.max() > 0
+        assert (b[:, 0] >= 0).all() and (b[:, 2] <= 1333).all() and (b[:, 1] >= 0).all() and (b[:, 3] <= 800).all()
+        assert (b[:, 2] >= b[:, 0]).all() and (b[:, 3] >= b[:, 1]).all()
+        assert (p[:-1] >= p[1:]).all() and (p > 0).all() and (p <= 1).all()        # NMS keeps score order
+        assert (out["obj_ids"][i] >= 0).all() and (out["obj_ids"][i] < 1600).all()
+        assert (out["attr_ids"][i] >= 0).all() and (out["attr_ids"][i] < 400).all()
+        assert (full["roi_features"][i, ppi[i]:] == 0).all()                        # rows past the count stay zero
+    assert len({tuple(out["obj_ids"][i].tolist()) for i in range(B)}) > 1           # images differ, so do detections
+    # an image's outputs do not depend on what else is in the batch: images 0-1 of the 32 == a batch of just those two
+    m(x[:2], shapes[:2])
+    two = m.forward_padded()
+    for k in full:
+        assert torch.equal(full[k][:2], two[k]), k
+    assert torch.equal(res4[:2], m.get_stage("res4"))
+    # res3/res4 as two half-batches on two streams (the default at this size) == one stream, at real size
+    m.set_option("backbone_streams", 1)
+    m(x, shapes)
+    one = m.forward_padded()
+    for k in full:
+        assert torch.equal(full[k], one[k]), k
+    assert torch.equal(res4, m.get_stage("res4"))
+    m.set_option("backbone_streams", 2)
+    # run-to-run reproducibility at real size
+    m(x, shapes)
+    for k in full:
+        assert torch.equal(full[k], m.forward_padded()[k]), k
+
+
+@pytest.fixture(scope="module")
+def one_image():
+    x = synthetic_images(1, 800, 1333, seed=0xF2C)
+    return torch.from_numpy(x), [[800, 1333]]
+
+
+def test_full_size_image_fp32_strict_vs_oracle(bench_model, one_image):
+    """One 800x1333 image, R = 300, D = 100: every stage of the strict mode against the oracle fed with the GPU's own
+    upstream tensors (indices bit-exact: 63 000 anchors -> 6000 -> 300; 300 RoIs -> detections), and the free-running
+    comparison of res4 / RoI features / outputs at 1e-3 (north_star)."""
+    cfg, sd, _ = bench_model
+    x, shapes = one_image
+    m = FRCNN(cfg, precision="fp32").load_state_dict(sd).eval()
+    out = m(x, torch.tensor(shapes))
+    oracle = FRCNNOracle(cfg, sd)
+    torch.set_num_threads(16)
+    res4, feat = stage_chain_check(m, out, oracle, shapes, tol=1e-4)
+    ref, st = oracle.forward(x, shapes, return_stages=True)
+    e_res4 = G.rel_err(res4, st["res4"])
+    print(f"\n[full size, fp32 strict vs oracle, free-running] res4 rel err {e_res4:.3e}")
+    assert e_res4 <= 1e-3
+    same = out["obj_ids"][0].cpu().tolist() == ref["obj_ids"][0].tolist()
+    print(f"[full size, fp32 strict vs oracle, free-running] detections identical: {same} ({int(out['preds_per_image'][0])})")
+    assert same
+    for k in ("roi_features", "boxes", "obj_probs", "attr_probs"):
+        e = G.rel_err(out[k][0].cpu(), ref[k][0])
+        print(f"[full size, fp32 strict vs oracle, free-running] {k} rel err {e:.3e}")
+        assert e <= 1e-3, k
+    np.testing.assert_array_equal(out["attr_ids"][0].cpu().numpy(), ref["attr_ids"][0].numpy())
+
+
+def test_full_size_image_fp16_fast_vs_emulating_oracle(bench_model, one_image):
+    """The benched mode on one full-size image: stage by stage against the fp16-emulating oracle at 1e-3 (the conv stages
+    at their real grids: 525-tile res4, 300-RoI head chunk), and its deviation from the fp32 oracle, reported; RoI features
+    of detections both runs agree on are held to 1e-3 (north_star)."""
+    cfg, sd, m = bench_model
+    x, shapes = one_image
+    out = m(x, torch.tensor(shapes))
+    torch.set_num_threads(16)
+    oracle16 = FRCNNOracle(cfg, sd, emulate="fp16")
+    res4 = nchw(m.get_stage("res4"))
+    e = G.rel_err(res4, oracle16.backbone(x))
+    print(f"\n[full size, fp16 vs fp16-emulating oracle, free-running backbone] res4 rel err {e:.3e}")
+    assert e <= 5e-3
+    stage_chain_check(m, out, oracle16, shapes, tol=1e-3)
+    ref, st = FRCNNOracle(cfg, sd).forward(x, shapes, return_stages=True)
+    print(f"[full size, fp16 vs fp32 oracle] res4 rel err {G.rel_err(res4, st['res4']):.3e}")
+    # detections are matched by box (the two runs rank 300 near-tied proposals independently)
+    gb, rb = out["boxes"][0].cpu(), ref["boxes"][0]
+    matched, worst = 0, 0.0
+    for i in range(len(gb)):
+        d = (rb - gb[i]).abs().max(dim=1).values
+        j = int(d.argmin())
+        if d[j] <= 1.0 and int(out["obj_ids"][0][i]) == int(ref["obj_ids"][0][j]):
+            matched += 1
+            worst = max(worst, G.rel_err(out["roi_features"][0][i].cpu(), ref["roi_features"][0][j]))
+    print(f"[full size, fp16 vs fp32 oracle] {matched} of {len(gb)} detections matched by box and class; "
+          f"worst RoI-feature rel err over them {worst:.3e}")
+    assert matched >= len(gb) // 2
+    assert worst <= 1e-3

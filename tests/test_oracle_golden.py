@@ -170,9 +170,14 @@ VARIANTS = {   # tools/gen_golden.py VARIANTS: configuration switches of the ref
 }
 
 
+VARIANTS_X152 = {   # tools/gen_golden.py VARIANTS_X152 (BASELINE configs[3] at its real depth / group count), e2e_x152.npz
+    "resnext152_32x8d": [("resnets", "depth", 152), ("resnets", "num_groups", 32), ("resnets", "width_per_group", 8)],
+}
+
+
 def variant_inputs(g, tag):
     n, h, w = g["nhw"].tolist()
-    cfg = vg_c4_config(depth=50, post_nms_topk=16, detections=6, overrides=VARIANTS[tag])
+    cfg = vg_c4_config(depth=50, post_nms_topk=16, detections=6, overrides={**VARIANTS, **VARIANTS_X152}[tag])
     sd = make_state_dict(cfg, seed=int(g["seed"]))
     x = torch.from_numpy(synthetic_images(n, h, w, seed=int(g["seed"])))
     shapes = g["shapes"].tolist()
@@ -182,11 +187,11 @@ def variant_inputs(g, tag):
     return cfg, sd, x, shapes
 
 
-@pytest.mark.parametrize("tag", list(VARIANTS))
+@pytest.mark.parametrize("tag", list(VARIANTS) + list(VARIANTS_X152))
 def test_e2e_config_variants(golden_dir, tag):
-    """ResNeXt groups / RES5HALVE / stride in the 3x3 (frcnn.py:217-219, 932, 942-952, 1345-1355): the oracle
-    against the reference's own end-to-end output for each switch."""
-    g = np.load(os.path.join(golden_dir, "e2e_variants.npz"))
+    """ResNeXt groups / RES5HALVE / stride in the 3x3 (frcnn.py:217-219, 932, 942-952, 1345-1355), and ResNeXt-152
+    32x8d at full depth (BASELINE configs[3]): the oracle against the reference's own end-to-end output for each."""
+    g = np.load(os.path.join(golden_dir, "e2e_x152.npz" if tag in VARIANTS_X152 else "e2e_variants.npz"))
     cfg, sd, x, shapes = variant_inputs(g, tag)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     out, st = FRCNNOracle(cfg, sd).forward(x, shapes, return_stages=True)

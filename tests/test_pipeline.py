@@ -79,9 +79,40 @@ def test_pipeline_writer_error_surfaces(tmp_path):
     exec(_FAKE, ns)
     from vltk_amd.pipeline import ExtractionPipeline
     pipe = ExtractionPipeline(ns["FakeModel"](), ns["fake_preprocess"], str(tmp_path / "t.arrow"), batch_size=2, visual_dim=8)
-    dup = ns["items"](0, 3) + ns["items"](1, 2) + ns["items"](3, 9)         # a duplicate imgid: the writer raises
-    with pytest.raises(ValueError, match="duplicate imgid"):
-        pipe.run(dup)
+    calls = []
+
+    def failing(*a):                      # the second batch cannot be written: the error must reach the caller of run()
+        calls.append(1)
+        if len(calls) == 2:
+            raise ValueError("no space left on device")
+    pipe.writer.write_batch = failing
+    with pytest.raises(ValueError, match="no space left"):
+        pipe.run(ns["items"](0, 9))
+
+
+def test_pipeline_duplicate_ids_are_skipped(tmp_path):
+    """The reference prints "skipping ..." for a repeated imgid (extraction.py:183-185); here the row really is skipped
+    and the run continues."""
+    ns = {}
+    sys.path.insert(0, ROOT)
+    exec(_FAKE, ns)
+    from vltk_amd.pipeline import ExtractionPipeline
+    path = str(tmp_path / "t.arrow")
+    pipe = ExtractionPipeline(ns["FakeModel"](), ns["fake_preprocess"], path, batch_size=2, visual_dim=8)
+    dup = ns["items"](0, 3) + ns["items"](1, 2) + ns["items"](3, 9)
+    assert pipe.run(dup) == path
+    ns["check"](path, 9)
+
+
+def test_pipeline_fewer_images_than_ranks_raises_before_any_collective(tmp_path):
+    ns = {}
+    sys.path.insert(0, ROOT)
+    exec(_FAKE, ns)
+    from vltk_amd.pipeline import ExtractionPipeline
+    pipe = ExtractionPipeline(ns["FakeModel"](), ns["fake_preprocess"], str(tmp_path / "t.arrow"), batch_size=2, visual_dim=8)
+    pipe.world = 4                        # as rank 0 of four
+    with pytest.raises(ValueError, match="every rank needs at least one image"):
+        pipe.run(ns["items"](0, 1), n_items=3)
 
 
 _WORKER = _FAKE + r"""

@@ -6,7 +6,7 @@ the uncalibrated base weights and records, per prediction head, the gain and
 bias that make its output zero-mean with the target std (see
 vltk_amd.weights.HEAD_TARGET_STD).  Output: vltk_amd/data/head_calib_*.npz.
 
-    python tools/calibrate_weights.py [--depth 101] [--seed 1234]
+    python tools/calibrate_weights.py [--depth 101] [--groups 1] [--width 64] [--seed 1234]
 """
 import argparse
 import os
@@ -27,8 +27,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--groups", type=int, default=1, help="RESNETS.NUM_GROUPS (ResNeXt)")
+    ap.add_argument("--width", type=int, default=64, help="RESNETS.WIDTH_PER_GROUP")
     a = ap.parse_args()
-    cfg = vg_c4_config(depth=a.depth, post_nms_topk=64, detections=36)
+    cfg = vg_c4_config(depth=a.depth, num_groups=a.groups, width_per_group=a.width, post_nms_topk=64, detections=36)
     sd = W.make_state_dict(cfg, a.seed, calibrated=False)
     o = FRCNNOracle(cfg, sd)
     x = torch.from_numpy(W.synthetic_images(2, 192, 256, seed=a.seed + 1))

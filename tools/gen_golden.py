@@ -296,19 +296,28 @@ VARIANTS = {
 }
 
 
-def variant_config_dict(tag, post_topk=16, det=6):
+# BASELINE configs[3]: ResNeXt-152 32x8d at its real depth and group count (small image, same seeded weights as bench.py
+# --arch x152: seed 1234, head calibration vltk_amd/data/head_calib_r152_g32x8_seed1234.npz); kept in its own file so the
+# other variants' fixture stays byte-identical
+VARIANTS_X152 = {
+    "resnext152_32x8d": [("resnets", "depth", 152), ("resnets", "num_groups", 32), ("resnets", "width_per_group", 8)],
+}
+
+
+def variant_config_dict(tag, post_topk=16, det=6, variants=None):
     d = vg_c4_config_dict(depth=50, post_nms_topk=post_topk, detections=det)
-    for sec, key, val in VARIANTS[tag]:
+    for sec, key, val in (variants or VARIANTS)[tag]:
         d[sec][key] = val
     return d
 
 
-def e2e_variants(ref, n=2, h=128, w=160, shapes=((128, 160), (112, 150)), seed=4321):
+def e2e_variants(ref, n=2, h=128, w=160, shapes=((128, 160), (112, 150)), seed=4321, variants=None, outfile="e2e_variants.npz"):
     """Compact end-to-end vectors of the reference for configuration switches the main fixture does not take:
     ResNeXt groups (frcnn.py:217-219, 942-952), RES5HALVE (:1345-1355), stride in the 3x3 (:932).  Weights are regenerated from the seed, never stored."""
     out = {"nhw": np.asarray([n, h, w]), "shapes": np.asarray(shapes), "seed": np.asarray(seed)}
-    for tag in VARIANTS:
-        cfg = Config(variant_config_dict(tag))
+    variants = variants or VARIANTS
+    for tag in variants:
+        cfg = Config(variant_config_dict(tag, variants=variants))
         sd = make_state_dict(cfg, seed=seed)
         net = ref.FRCNN(cfg).eval()
         net.load_state_dict(to_torch_sd(sd), strict=True)
@@ -339,8 +348,8 @@ def e2e_variants(ref, n=2, h=128, w=160, shapes=((128, 160), (112, 150)), seed=4
         print(tag, "preds", out[f"{tag}/preds_per_image"], "res4 max %.2f" % float(st["res4"].max()),
               "feat max %.2f" % float(st["pooled"].max()), "min cls margin %.2e" % out[f"{tag}/cls_margin"].min(),
               "obj ids", out[f"{tag}/obj_ids_0"][:6])
-    np.savez_compressed(os.path.join(OUT, "e2e_variants.npz"), **out)
-    print("e2e_variants.npz:", len(out), "arrays")
+    np.savez_compressed(os.path.join(OUT, outfile), **out)
+    print(outfile + ":", len(out), "arrays")
 
 
 def fpn_ops(ref):
@@ -427,6 +436,12 @@ def fpn_ops(ref):
 if __name__ == "__main__" and "--fpn" in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     fpn_ops(load_reference())
+    sys.exit(0)
+
+if __name__ == "__main__" and "--x152" in sys.argv:
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    e2e_variants(load_reference(), seed=1234, variants=VARIANTS_X152, outfile="e2e_x152.npz")
     sys.exit(0)
 
 if __name__ == "__main__" and "--variants" in sys.argv:

@@ -88,18 +88,34 @@ class ExtractionWriter:
         if feats.shape[1:] != (self.D, self.F):
             raise ValueError(f"features must be [B, {self.D}, {self.F}], got {feats.shape}")
         B = feats.shape[0]
-        for i, iid in enumerate(imgids):
-            iid = str(iid)
-            if iid in self.img_to_row:
-                print(f"skipping {iid}. Already written to table")      # extraction.py:183-185 (and really skip)
-                raise ValueError(f"duplicate imgid {iid}")
-            self.img_to_row[iid] = self.rows + i
+        ids = [str(i) for i in imgids]
+        if len(ids) != B:
+            raise ValueError(f"{len(ids)} imgids for {B} rows")
+        # duplicates: the reference prints "skipping ..." and then writes the row anyway, leaving an orphan row behind
+        # the re-pointed img_to_row_map entry (extraction.py:183-185).  Here the row really is skipped; nothing is
+        # mutated before the whole batch has been looked at.
+        keep, fresh = [], set()
+        for i, iid in enumerate(ids):
+            if iid in self.img_to_row or iid in fresh:
+                print(f"skipping {iid}. Already written to table")
+                continue
+            fresh.add(iid)
+            keep.append(i)
+        if not keep:
+            return
+        attr_ids = np.asarray(attr_ids).reshape(B, self.D)
+        object_ids = np.asarray(object_ids).reshape(B, self.D)
+        boxes = np.asarray(boxes).reshape(B, self.D, 4)
+        if len(keep) != B:
+            feats, attr_ids, object_ids, boxes = feats[keep], attr_ids[keep], object_ids[keep], boxes[keep]
+            ids = [ids[i] for i in keep]
+            B = len(keep)
         batch = pa.record_batch([
-            _list1d(np.asarray(attr_ids).reshape(B, self.D)), _list2d(np.asarray(boxes).reshape(B, self.D, 4)),
-            _list2d(feats), pa.array([str(i) for i in imgids], pa.string()),
-            _list1d(np.asarray(object_ids).reshape(B, self.D)),
+            _list1d(attr_ids), _list2d(boxes), _list2d(feats), pa.array(ids, pa.string()), _list1d(object_ids),
         ], schema=self.schema)
         self._writer.write_batch(batch)
+        for i, iid in enumerate(ids):
+            self.img_to_row[iid] = self.rows + i
         self.rows += B
 
     def close(self):

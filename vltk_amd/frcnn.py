@@ -70,35 +70,50 @@ def _c_config(cfg, precision):
 _TORCH_DT = {L.VK_F32: torch.float32, L.VK_F16: torch.float16, L.VK_I64: torch.int64, L.VK_I32: torch.int32}
 
 
-class PendingForward:
-    """A forward in flight (FRCNN.forward_async)."""
+class _Ticket:
+    """State of one forward in flight; the model keeps these in issue order (`FRCNN._open`)."""
 
-    def __init__(self, model, ticket, block, hw, images):
-        self.model, self.ticket, self.block, self.hw = model, ticket, block, hw
-        self._images = images          # keeps the input alive until the kernels have read it
-        self._done = False
+    __slots__ = ("ticket", "block", "images", "done", "error")
+
+    def __init__(self, ticket, block, images):
+        self.ticket, self.block = ticket, block
+        self.images = images           # keeps the input alive until the kernels have read it
+        self.done, self.error = False, None
+
+
+class PendingForward:
+    """A forward in flight (FRCNN.forward_async).  Handles are waited for in issue order; a handle that is DROPPED
+    (garbage-collected) without a wait closes its own ticket and every older one that is still open, in order, so an
+    out-of-order drop cannot leave tickets open (the results of those older forwards stay available to their handles)."""
+
+    def __init__(self, model, state, hw):
+        self.model, self._state, self.hw = model, state, hw
+
+    @property
+    def ticket(self):
+        return self._state.ticket
+
+    @property
+    def block(self):
+        return self._state.block
 
     def wait_raw(self):
         """Finish the forward; returns the fixed-capacity OutputBlock ([N, D, ...] device tensors)."""
-        if not self._done:
-            try:
-                L.call("vk_forward_end", self.model._h, C.c_int64(self.ticket))
-            except ValueError:          # out of order: the ticket is still open
-                raise
-            except Exception:           # the forward finished and failed (non-finite boxes, frcnn.py:148)
-                self._done, self._images = True, None
-                raise
-            self._done, self._images = True, None
-            self.model._last_padded = self.block
-        return self.block
+        st = self._state
+        if not st.done:
+            self.model._end(st)         # ValueError if an older forward is still open (it stays open)
+        if st.error is not None:
+            raise st.error              # the forward finished and failed (non-finite boxes, frcnn.py:148)
+        self.model._last_padded = st.block
+        return st.block
 
     def wait(self, **kwargs):
         return FRCNN._format(self.wait_raw(), self.hw, **kwargs)
 
-    def __del__(self):                 # a dropped handle must not leave its ticket open
+    def __del__(self):
         try:
-            if not self._done and self.model._h:
-                self.wait_raw()
+            if not self._state.done and self.model._h:
+                self.model._close_through(self._state)
         except Exception:
             pass
 
@@ -121,6 +136,7 @@ class FRCNN:
         self.roi_outputs = ROIOutputs(cfg)
         self.training = False
         self._h = C.c_void_p()
+        self._open = []                # _Ticket of every forward in flight, oldest first
         L.call("vk_create", C.byref(_c_config(cfg, self.precision)), dev.index, C.byref(self._h))
         self._finalized = False
 
@@ -287,7 +303,29 @@ class FRCNN:
         L.call("vk_forward_begin", self._h, images.data_ptr(), N, H, W, hw.ctypes.data_as(C.c_void_p),
                sc.ctypes.data_as(C.c_void_p) if sc is not None else None, C.byref(rp), C.byref(out),
                C.c_void_p(stream), C.byref(ticket))
-        return PendingForward(self, ticket.value, bufs, hw, images)
+        st = _Ticket(ticket.value, bufs, images)
+        self._open.append(st)
+        return PendingForward(self, st, hw)
+
+    def _end(self, st):
+        """vk_forward_end for one ticket.  Out of order -> ValueError from the library, nothing changes."""
+        try:
+            L.call("vk_forward_end", self._h, C.c_int64(st.ticket))
+        except ValueError:
+            raise
+        except Exception as e:          # the forward itself ended; its assertion failed
+            st.error = e
+        st.done, st.images = True, None
+        if st in self._open:
+            self._open.remove(st)
+
+    def _close_through(self, st):
+        """End every open forward up to and including `st`, oldest first."""
+        while self._open:
+            head = self._open[0]
+            self._end(head)
+            if head is st:
+                break
 
     inference = forward
 

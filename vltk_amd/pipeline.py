@@ -117,6 +117,10 @@ class ExtractionPipeline:
                 raise ValueError("n_items (the global image count) is required with more than one rank")
             n_items = len(items)
         spans = [shard_indices(n_items, r, self.world) for r in range(self.world)]
+        if n_items < self.world:
+            # every rank sees the same numbers and raises here, before any thread or collective exists: a rank with an
+            # empty shard could not pad its steps (no image to repeat) and its peers would wait for it in the all-gather
+            raise ValueError(f"{n_items} image(s) for {self.world} ranks: every rank needs at least one image")
         n_steps = max((hi - lo + self.B - 1) // self.B for lo, hi in spans)
         dev = self.model.device
         load_q = queue.Queue(maxsize=2)
