@@ -333,6 +333,23 @@ int vk_mean_pool(const void *x, int K, int S, int C, float *out, vk_dtype dt, vo
 int vk_box_decode(const float *deltas, const float *boxes, int M, int k, const float *weights4_host,
                   float *out, void *stream);
 
+/* Pieces of the box head for callers that compose one themselves (the FPN detector, vltk_amd/frcnn_fpn.py):
+ * vk_make_rois       <- convert_boxes_to_pooler_format frcnn.py:426-441: boxes [N,R,4] -> rois [N*R,5] (batch,x1,y1,x2,y2)
+ * vk_softmax_argmax  <- ROIOutputs._predict_objs / _predict_attrs :1252-1260: per row soft-max over the first n_softmax
+ *                       logits, max / arg-max of the probabilities over the first n_argmax; raw_argmax_out (optional) =
+ *                       arg-max of the raw logits over n_softmax (`scores.max(-1)` incl. background, :1732)
+ * vk_concat_embed    <- `cat([roi_features, cls_embedding(max_class)], -1)` :1733-1734: out[k] = [ (dt)features[k][0:F] |
+ *                       emb[cls[k]][0:E] ]; E == 0: a plain f32 -> dt conversion of the features
+ * vk_chosen_deltas   <- bbox_pred :1730 for the arg-max class only: out[k][j] = bias[r] + <x[k], w_rows[r]>,
+ *                       r = 4 * cls[k] + j (class-specific) or j (agnostic); w_rows [4C or 4, F] in dt, unpadded rows */
+int vk_make_rois(const float *boxes, int N, int R, float *rois, void *stream);
+int vk_softmax_argmax(const float *logits, int ld, int K, int n_softmax, int n_argmax, float *prob_out,
+                      int32_t *cls_out, int32_t *raw_argmax_out, void *stream);
+int vk_concat_embed(const float *features, int F, const void *emb, int E, const int32_t *cls, int K, void *out,
+                    vk_dtype dt, void *stream);
+int vk_chosen_deltas(const void *x, int ldx, const void *w_rows, const float *bias, const int32_t *cls,
+                     int cls_agnostic, int F, int K, float *out, vk_dtype dt, void *stream);
+
 /* ROIOutputs.inference (frcnn.py:1262-1294) + do_nms (:116-143), per image:
  *   obj_logits [K,C+1] f32 (row stride ld_obj), attr_logits [K,A+1] f32 (ld_attr),
  *   box_deltas: either full [K,4C] (ld_box=4C, chosen_only=0) or only the arg-max class's

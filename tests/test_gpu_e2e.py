@@ -142,9 +142,10 @@ def test_e2e_fp16_fast_vs_emulating_oracle(setup, golden):
 
 
 def fp16_vs_reference_golden(m, out, golden, n):
-    """The benched (fp16) mode held to north_star's 1e-3 against the fp32 REFERENCE golden: identical detections, RoI
-    features, class / attribute probabilities and boxes <= 1e-3; res4 (an intermediate 100 fp16-storage layers deep,
-    measured 1.8e-3) is reported and bounded at 5e-3."""
+    """The benched (fp16) mode held to north_star's 1e-3 against the fp32 REFERENCE golden: identical detections; RoI
+    features, boxes, and the class / attribute LOGITS of every proposal <= 1e-3 (north_star: "RoI features and box/attr
+    logits ... within 1e-3").  Reported with looser bounds: res4 (an intermediate map 100 fp16-storage layers deep, measured
+    1.7e-3) and the soft-max probabilities (logits of std 4 turn a 1e-3 logit error into ~3e-3 of the top probability)."""
     dev = G.rel_err(nchw(m.get_stage("res4")), golden["res4"])
     print(f"\n[fp16 vs fp32 reference] res4 rel err {dev:.3e} (reported; intermediate map)")
     assert dev <= 5e-3
@@ -153,10 +154,34 @@ def fp16_vs_reference_golden(m, out, golden, n):
     for i in range(n):
         np.testing.assert_array_equal(out["obj_ids"][i].cpu().numpy(), golden[f"obj_ids_{i}"])
         np.testing.assert_array_equal(out["attr_ids"][i].cpu().numpy(), golden[f"attr_ids_{i}"])
-        for k in ("roi_features", "obj_probs", "attr_probs", "boxes"):
+        for k, tol in (("roi_features", 1e-3), ("boxes", 1e-3), ("obj_probs", 5e-3), ("attr_probs", 5e-3)):
             e = G.rel_err(out[k][i].cpu(), golden[f"{k}_{i}"])
             print(f"[fp16 vs fp32 reference] image {i} {k} rel err {e:.3e}")
-            assert e <= 1e-3, (k, i, e)
+            assert e <= tol, (k, i, e)
+    # logits of every proposal: rows are matched by proposal box (the two runs may order near-tied proposals differently)
+    R = m.config.RPN.POST_NMS_TOPK_TEST
+    pb, pc = m.get_stage("proposal_boxes").cpu(), m.get_stage("proposal_counts").cpu()
+    ol, al = m.get_stage("obj_logits").cpu(), m.get_stage("attr_logits").cpu()
+    g_ol, g_al = torch.from_numpy(golden["obj_logits"]), torch.from_numpy(golden["attr_logits"])
+    C1, A1 = g_ol.shape[1], g_al.shape[1]
+    rows_gpu, rows_ref, off = [], [], 0
+    for i in range(n):
+        gb = torch.from_numpy(golden[f"proposal_boxes_{i}"])
+        for r in range(int(pc[i])):
+            d = (gb - pb[i, r]).abs().max(dim=1).values
+            j = int(d.argmin())
+            if d[j] <= 0.05:
+                rows_gpu.append(i * R + r)
+                rows_ref.append(off + j)
+        off += len(gb)
+    assert len(rows_gpu) >= 0.9 * off, (len(rows_gpu), off)
+    a, b = ol[rows_gpu][:, :C1], g_ol[rows_ref]
+    e_obj = G.rel_err(a, b)
+    same = a.argmax(-1) == b.argmax(-1)             # the attribute branch embeds the arg-max class (frcnn.py:1732-1733)
+    e_attr = G.rel_err(al[rows_gpu][:, :A1][same], g_al[rows_ref][same])
+    print(f"[fp16 vs fp32 reference] {len(rows_gpu)} of {off} proposals matched by box; obj_logits rel err {e_obj:.3e}, "
+          f"attr_logits rel err {e_attr:.3e} ({int(same.sum())} rows with the same arg-max class)")
+    assert e_obj <= 1e-3 and e_attr <= 1e-3
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 1e-3)])

@@ -121,6 +121,10 @@ SIGNATURES = {
     "vk_roi_pool": (_I, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _P]),
     "vk_mean_pool": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "vk_box_decode": (_I, [_P, _P, _I, _I, C.POINTER(_F), _P, _P]),
+    "vk_make_rois": (_I, [_P, _I, _I, _P, _P]),
+    "vk_softmax_argmax": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "vk_concat_embed": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P]),
+    "vk_chosen_deltas": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "vk_roi_outputs": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, C.POINTER(_F),
                             C.POINTER(vk_roi_params), C.POINTER(vk_outputs), _P, _P, _P]),
 }

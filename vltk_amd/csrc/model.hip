@@ -1346,6 +1346,34 @@ int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *fl
     return VK_OK;
 }
 
+// ---- pieces of FastRCNNOutputLayers.forward (frcnn.py:1726-1740) / ROIPooler input format (:426-441) for callers that
+// compose a box head themselves (the FPN detector, vltk_amd/frcnn_fpn.py) ----
+int vk_make_rois(const float *boxes, int N, int R, float *rois, void *stream) {
+    VK_REQUIRE(boxes && rois && N > 0 && R > 0, VK_EINVAL, "make_rois: bad arguments");
+    return launch_make_rois(boxes, N, R, rois, (hipStream_t)stream);
+}
+
+int vk_softmax_argmax(const float *logits, int ld, int K, int n_softmax, int n_argmax, float *prob_out, int32_t *cls_out,
+                      int32_t *raw_argmax_out, void *stream) {
+    VK_REQUIRE(logits && prob_out && cls_out && K >= 0 && n_softmax >= 1 && n_argmax >= 1 && n_argmax <= n_softmax && ld >= n_softmax,
+               VK_EINVAL, "softmax_argmax: bad arguments");
+    return launch_softmax_argmax(logits, ld, K, n_softmax, n_argmax, prob_out, cls_out, raw_argmax_out, (hipStream_t)stream);
+}
+
+int vk_concat_embed(const float *features, int F, const void *emb, int E, const int32_t *cls, int K, void *out, vk_dtype dt,
+                    void *stream) {
+    VK_REQUIRE(features && out && F > 0 && E >= 0 && K >= 0 && (E == 0 || (emb && cls)), VK_EINVAL, "concat_embed: bad arguments");
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "concat_embed: dtype must be f16 or f32");
+    return launch_concat_embed(features, emb, cls, F, E, K, out, dt, (hipStream_t)stream);
+}
+
+int vk_chosen_deltas(const void *x, int ldx, const void *w_rows, const float *bias, const int32_t *cls, int cls_agnostic, int F,
+                     int K, float *out, vk_dtype dt, void *stream) {
+    VK_REQUIRE(x && w_rows && bias && out && (cls || cls_agnostic) && F > 0 && ldx >= F && K >= 0, VK_EINVAL, "chosen_deltas: bad arguments");
+    VK_REQUIRE(dt == VK_F16 || dt == VK_F32, VK_EINVAL, "chosen_deltas: dtype must be f16 or f32");
+    return launch_chosen_deltas(x, ldx, w_rows, bias, cls, cls_agnostic, F, K, out, dt, (hipStream_t)stream);
+}
+
 int vk_roi_outputs(const float *obj_logits, int ld_obj, const float *attr_logits, int ld_attr, const float *box_deltas,
                    int ld_box, int chosen_only, const float *proposals, const int32_t *counts, const float *features, int F,
                    int N, int R, int C, int A, const int32_t *image_hw, const float *scales_yx_dev,
