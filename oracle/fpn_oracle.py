@@ -117,3 +117,108 @@ def multilevel_proposals(objs, deltas, cell_anchors, strides, image_shapes, pre_
         k = batched_nms(boxes, scores, lvl, nms_thresh)[:post_topk]
         res.append((boxes[k], scores[k]))
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The FPN detector end to end (build extension; PARITY UNPINNED vs the reference, which has no FPN model).  Composition:
+# detectron2's standard ResNet-FPN Faster R-CNN -- bottom-up ResNet res2..res5 (the reference's own BottleneckBlock
+# :903-979 / BasicStem :857-888 arithmetic, restated in FRCNNOracle), FPN neck (above), one RPNHead :1513-1572 shared by the
+# levels, find_top_rpn_proposals :264-390 over the levels (above), ROIPooler's level loop :1200-1224 with RoIAlign,
+# a 2-FC box head, and the reference's own FastRCNNOutputLayers :1676-1740 / ROIOutputs :1227-1302 on its features.
+# ---------------------------------------------------------------------------------------------------------------------
+from collections import OrderedDict            # noqa: E402
+
+from .frcnn_oracle import FRCNNOracle, _h      # noqa: E402
+
+
+class FPNDetectorOracle(FRCNNOracle):
+    STRIDES = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+
+    def stem(self, x):                                        # BasicStem frcnn.py:872-879, detectron2 key prefix
+        if self.emulate:
+            x = _h(x)
+        x = self._conv_bn(x, "backbone.bottom_up.stem.conv1", stride=2, padding=3, relu=True)
+        if self.cfg.MODEL.MAX_POOL:
+            return F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+    def backbone(self, images, return_stages=False):          # ResNet.forward :1076-1090 with res2..res5 as outputs
+        x = self.stem(images)
+        stages = OrderedDict()
+        for si, name in enumerate(("res2", "res3", "res4", "res5")):
+            for b in range(self.nblocks[si]):
+                first_stride = 1 if si == 0 else 2            # frcnn.py:237
+                x = self.bottleneck(x, f"backbone.bottom_up.{name}.{b}", first_stride if b == 0 else 1)
+            stages[name] = x
+        return stages
+
+    def _conv_b(self, x, prefix, padding=0):
+        return self._conv_bias(x, prefix, padding=padding, relu=False)
+
+    def neck(self, stages):
+        """[C2..C5] -> [P2..P5, P6] (fpn_neck above, with the fast mode's f16 storage roundings when emulating)."""
+        feats = [stages[k] for k in ("res2", "res3", "res4", "res5")]
+        q = _h if self.emulate else (lambda t: t)
+        prev = self._conv_b(feats[-1], "backbone.fpn_lateral5")
+        results = [self._conv_b(prev, "backbone.fpn_output5", padding=1)]
+        for i, lvl in zip((2, 1, 0), (4, 3, 2)):
+            top_down = F.interpolate(prev, scale_factor=2.0, mode="nearest")
+            lat = self._conv_b(feats[i], f"backbone.fpn_lateral{lvl}")
+            prev = q(lat + top_down[:, :, :lat.shape[2], :lat.shape[3]])
+            results.insert(0, self._conv_b(prev, f"backbone.fpn_output{lvl}", padding=1))
+        results.append(last_level_maxpool(results[-1]))
+        return results
+
+    def rpn_heads(self, pyramid):
+        return [self.rpn_head(p) for p in pyramid]            # one head, every level (RPNHead.forward :1561-1572)
+
+    def proposals(self, heads, image_shapes):
+        cfg = self.cfg
+        n = len(heads)
+        cells = [self.sd[f"proposal_generator.anchor_generator.cell_anchors.{i}"] for i in range(n)]
+        strides = [4 * 2 ** i for i in range(n)]
+        return multilevel_proposals([h[0] for h in heads], [h[1] for h in heads], cells, strides, image_shapes,
+                                    cfg.RPN.PRE_NMS_TOPK_TEST, cfg.RPN.POST_NMS_TOPK_TEST, cfg.RPN.NMS_THRESH,
+                                    cfg.PROPOSAL_GENERATOR.MIN_SIZE, cfg.RPN.BBOX_REG_WEIGHTS, cfg.ANCHOR_GENERATOR.OFFSET)
+
+    def box_pool(self, pyramid, proposal_boxes):
+        rois = torch.cat([torch.cat((torch.full((len(b), 1), float(i)), b), dim=1) for i, b in enumerate(proposal_boxes)], dim=0)
+        P, sr = self.cfg.ROI_BOX_HEAD.POOLER_RESOLUTION, self.cfg.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO
+        pooled, lv = multilevel_pool(pyramid[:4], [1 / 4, 1 / 8, 1 / 16, 1 / 32], rois, P, "align", sr, True)
+        return (_h(pooled) if self.emulate else pooled), lv
+
+    def box_head(self, pooled):
+        """flatten (c, y, x) -> fc1 -> ReLU -> fc2 -> ReLU (detectron2 FastRCNNConvFCHead with NUM_FC fully connected layers);
+        the last layer's output stays f32 (it is `roi_features`)."""
+        q = _h if self.emulate else (lambda t: t)
+        x = torch.flatten(pooled, start_dim=1)
+        nfc = self.cfg.ROI_BOX_HEAD.NUM_FC
+        for i in range(nfc):
+            p = f"roi_heads.box_head.fc{i + 1}"
+            x = F.relu(F.linear(q(x), q(self.sd[p + ".weight"])) + self.sd[p + ".bias"])
+            if i + 1 < nfc:
+                x = q(x)
+        return x
+
+    @torch.no_grad()
+    def forward(self, images, image_shapes, scales_yx=None, return_stages=False):
+        images = torch.as_tensor(images, dtype=torch.float32)
+        image_shapes = [tuple(int(v) for v in s) for s in np.asarray(image_shapes).tolist()]
+        st = OrderedDict()
+        st["stages"] = self.backbone(images)
+        st["pyramid"] = self.neck(st["stages"])
+        st["rpn"] = self.rpn_heads(st["pyramid"])
+        props = self.proposals(st["rpn"], image_shapes)
+        proposal_boxes = [p[0] for p in props]
+        st["proposal_boxes"], st["proposal_logits"] = proposal_boxes, [p[1] for p in props]
+        st["pooled"], st["levels"] = self.box_pool(st["pyramid"], proposal_boxes)
+        feat = self.box_head(st["pooled"])
+        st["box_features"] = feat
+        obj_logits, attr_logits, box_deltas = self.predictor(feat)
+        st["obj_logits"], st["attr_logits"], st["box_deltas"] = obj_logits, attr_logits, box_deltas
+        res = self.roi_outputs(obj_logits, attr_logits, box_deltas, proposal_boxes, feat, image_shapes, scales_yx)
+        boxes, classes, probs, attrs, attr_probs, feats, ids = map(list, zip(*res))
+        out = OrderedDict(obj_ids=classes, obj_probs=probs, attr_ids=attrs, attr_probs=attr_probs, boxes=boxes,
+                          preds_per_image=torch.tensor([len(b) for b in boxes]), roi_features=feats)
+        st["keep_ids"] = ids
+        return (out, st) if return_stages else out

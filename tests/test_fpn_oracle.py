@@ -70,3 +70,30 @@ def test_multilevel_proposals_vs_reference(g):
     for i, (b, s_) in enumerate(res):
         np.testing.assert_array_equal(s_.numpy(), g[f"mlrpn/logits_{i}"])
         np.testing.assert_allclose(b.numpy(), g[f"mlrpn/boxes_{i}"], rtol=0, atol=1e-4)
+
+
+def test_fpn_detector_oracle_and_weights():
+    """The FPN detector's config, key layout and oracle (build extension, parity unpinned vs the reference): the oracle runs
+    end to end on CPU, uses several pyramid levels, its fp16-emulating twin stays close, and FRCNN(cfg) picks the FPN class."""
+    import torch
+    from oracle.fpn_oracle import FPNDetectorOracle
+    from vltk_amd.config import fpn_config, is_fpn, vg_c4_config
+    from vltk_amd.weights import make_state_dict, synthetic_images
+    cfg = fpn_config(depth=50, post_nms_topk=40, pre_nms_topk=200, detections=6)
+    assert is_fpn(cfg) and not is_fpn(vg_c4_config())
+    sd = make_state_dict(cfg, seed=3)
+    assert sd["roi_heads.box_head.fc1.weight"].shape == (1024, 256 * 7 * 7)
+    assert sd["roi_heads.box_predictor.fc_attr.weight"].shape == (256, 1024 + 128)       # sized from input_size, frcnn.py:1711-1719
+    assert sd["backbone.fpn_lateral5.weight"].shape == (256, 2048, 1, 1)
+    assert sd["proposal_generator.anchor_generator.cell_anchors.4"].shape == (3, 4)
+    x = torch.from_numpy(synthetic_images(2, 256, 320, seed=5))
+    shapes = [[256, 320], [240, 300]]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out, st = FPNDetectorOracle(cfg, sd).forward(x, shapes, return_stages=True)
+    assert [tuple(p.shape[2:]) for p in st["pyramid"]] == [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)]
+    assert out["preds_per_image"].tolist() == [6, 6] and out["roi_features"][0].shape == (6, 1024)
+    assert len(torch.unique(st["levels"])) >= 2
+    assert len(set(out["obj_ids"][0].tolist())) > 1                  # calibrated heads: not one class everywhere
+    st16 = FPNDetectorOracle(cfg, sd, emulate="fp16").backbone(x)
+    for k in st16:
+        assert float((st16[k] - st["stages"][k]).abs().max() / st["stages"][k].abs().max()) < 5e-3, k

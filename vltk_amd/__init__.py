@@ -12,7 +12,7 @@ import os as _os
 # (measured: 374 instead of 402 images/s).  Takes effect only if HIP has not been initialised yet; an explicit value wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-from .config import Config, vg_c4_config, vg_c4_config_dict  # noqa: F401
+from .config import Config, fpn_config, fpn_config_dict, vg_c4_config, vg_c4_config_dict  # noqa: F401
 from .weights import make_state_dict, synthetic_images  # noqa: F401
 
 

@@ -133,3 +133,37 @@ def vg_c4_config(overrides=(), **kw):
     for sec, key, val in overrides:
         d[sec][key] = val
     return Config(d)
+
+
+def fpn_config_dict(depth=101, num_groups=1, width_per_group=64, post_nms_topk=1000, pre_nms_topk=1000, detections=36,
+                    device="cpu"):
+    """ResNet-FPN Faster R-CNN in detectron2's standard layout (what BASELINE.json's configs name: "ResNet-101-FPN",
+    "ResNeXt-152-FPN").  The reference has no FPN model -- only fragments (frcnn.py:444-460, 825-854, 1200-1224) -- so this
+    is a build extension, PARITY UNPINNED vs the reference end to end.  Same key names as the C4 config; the multi-level
+    switches are `rpn.in_features` / `roi_heads.in_features` (several levels), `fpn.*`, per-level anchor `sizes`,
+    `roi_box_head.{pooler_type, num_fc, fc_dim}`."""
+    d = vg_c4_config_dict(depth=depth, num_groups=num_groups, width_per_group=width_per_group,
+                          post_nms_topk=post_nms_topk, detections=detections, device=device)
+    d["model"]["max_pool"] = False            # torchvision-style stem pool (pad 1), as detectron2's FPN models
+    d["resnets"]["out_features"] = ["res2", "res3", "res4", "res5"]
+    d["fpn"] = {"in_features": ["res2", "res3", "res4", "res5"], "out_channels": 256, "fuse_type": "sum"}
+    d["anchor_generator"]["sizes"] = [[32], [64], [128], [256], [512]]
+    d["proposal_generator"]["hidden_channels"] = -1
+    d["rpn"]["in_features"] = ["p2", "p3", "p4", "p5", "p6"]
+    d["rpn"]["pre_nms_topk_test"] = pre_nms_topk
+    d["roi_heads"]["in_features"] = ["p2", "p3", "p4", "p5"]
+    d["roi_box_head"].update({"pooler_resolution": 7, "pooler_sampling_ratio": 0, "pooler_type": "ROIAlignV2",
+                              "num_fc": 2, "fc_dim": 1024})
+    return d
+
+
+def fpn_config(overrides=(), **kw):
+    d = fpn_config_dict(**kw)
+    for sec, key, val in overrides:
+        d[sec][key] = val
+    return Config(d)
+
+
+def is_fpn(cfg):
+    """Several RPN input levels = the FPN detector (frcnn_fpn.py); one = the reference's C4 model (frcnn.py)."""
+    return len(cfg.RPN.IN_FEATURES) > 1

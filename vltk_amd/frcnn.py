@@ -119,6 +119,13 @@ class PendingForward:
 
 
 class FRCNN:
+    def __new__(cls, cfg=None, *a, **k):
+        # several RPN input levels = the FPN detector (frcnn_fpn.py, a build extension); one = the reference's C4 model
+        if cls is FRCNN and cfg is not None and len(cfg.RPN.IN_FEATURES) > 1:
+            from .frcnn_fpn import FRCNNFPN
+            return object.__new__(FRCNNFPN)
+        return object.__new__(cls)
+
     def __init__(self, cfg, precision=None, device=None):
         if not torch.cuda.is_available():
             raise RuntimeError("vltk_amd.FRCNN needs an AMD GPU (HIP device); there is no CPU fallback")

@@ -103,13 +103,59 @@ def layer_spec(cfg):
     return spec
 
 
+def fpn_layer_spec(cfg):
+    """The FPN detector's parametrised layers in detectron2's key layout (backbone.bottom_up.*, backbone.fpn_lateral{2..5},
+    backbone.fpn_output{2..5}, proposal_generator.rpn_head.*, roi_heads.box_head.fc{1,2}, roi_heads.box_predictor.*)."""
+    r = cfg.RESNETS
+    groups, wpg = r.NUM_GROUPS, r.WIDTH_PER_GROUP
+    stem_c, res2_c = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS
+    nblocks = BLOCKS_PER_STAGE[r.DEPTH]
+    spec = [("backbone.bottom_up.stem.conv1", (stem_c, len(cfg.MODEL.PIXEL_MEAN), 7, 7), "conv_bn")]
+    cin, cout, cmid = stem_c, res2_c, groups * wpg
+    stage_c = []
+    for si, stage in enumerate(("res2", "res3", "res4", "res5")):
+        for b in range(nblocks[si]):
+            spec += _bottleneck_spec(f"backbone.bottom_up.{stage}.{b}", cin, cmid, cout, groups, cin != cout)
+            cin = cout
+        stage_c.append(cout)
+        cout *= 2
+        cmid *= 2
+    fc = cfg.FPN.OUT_CHANNELS
+    for lvl, c in zip((2, 3, 4, 5), stage_c):
+        spec.append((f"backbone.fpn_lateral{lvl}", (fc, c, 1, 1), "conv_bias_lin"))
+        spec.append((f"backbone.fpn_output{lvl}", (fc, fc, 3, 3), "conv_bias_lin"))
+    hid = cfg.PROPOSAL_GENERATOR.HIDDEN_CHANNELS
+    hid = fc if hid == -1 else hid
+    A = len(cfg.ANCHOR_GENERATOR.SIZES[0]) * len(cfg.ANCHOR_GENERATOR.ASPECT_RATIOS[0])
+    spec += [
+        ("proposal_generator.rpn_head.conv", (hid, fc, 3, 3), "conv_bias"),
+        ("proposal_generator.rpn_head.objectness_logits", (A, hid, 1, 1), "conv_bias_obj"),
+        ("proposal_generator.rpn_head.anchor_deltas", (4 * A, hid, 1, 1), "conv_bias_delta"),
+    ]
+    P, fcd = cfg.ROI_BOX_HEAD.POOLER_RESOLUTION, cfg.ROI_BOX_HEAD.FC_DIM
+    cin = fc * P * P
+    for i in range(cfg.ROI_BOX_HEAD.NUM_FC):
+        spec.append((f"roi_heads.box_head.fc{i + 1}", (fcd, cin), "fc"))
+        cin = fcd
+    C = cfg.ROI_HEADS.NUM_CLASSES
+    nb = 1 if cfg.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG else C
+    spec += [("roi_heads.box_predictor.cls_score", (C + 1, fcd), "fc_cls"),
+             ("roi_heads.box_predictor.bbox_pred", (nb * 4, fcd), "fc_box")]
+    if cfg.ROI_BOX_HEAD.ATTR:            # FastRCNNOutputLayers sizes everything from input_size (frcnn.py:1711-1719)
+        spec += [("roi_heads.box_predictor.cls_embedding", (C + 1, fcd // 8), "embedding"),
+                 ("roi_heads.box_predictor.fc_attr", (fcd // 4, fcd + fcd // 8), "fc"),
+                 ("roi_heads.box_predictor.attr_score", (cfg.ROI_BOX_HEAD.NUM_ATTRS + 1, fcd // 4), "fc_cls")]
+    return spec
+
+
 def _rng(seed, name):
     return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
 
 
 def calib_path(cfg, seed):
     r = cfg.RESNETS
-    return os.path.join(_CALIB_DIR, f"head_calib_r{r.DEPTH}_g{r.NUM_GROUPS}x{r.WIDTH_PER_GROUP}_seed{seed}.npz")
+    fpn = "_fpn" if len(cfg.RPN.IN_FEATURES) > 1 else ""
+    return os.path.join(_CALIB_DIR, f"head_calib_r{r.DEPTH}_g{r.NUM_GROUPS}x{r.WIDTH_PER_GROUP}{fpn}_seed{seed}.npz")
 
 
 def make_state_dict(cfg, seed=1234, calibrated=True):
@@ -137,12 +183,13 @@ def make_state_dict(cfg, seed=1234, calibrated=True):
 
 def _base_state_dict(cfg, seed):
     sd = OrderedDict()
-    for prefix, shape, kind in layer_spec(cfg):
+    fpn = len(cfg.RPN.IN_FEATURES) > 1
+    for prefix, shape, kind in (fpn_layer_spec(cfg) if fpn else layer_spec(cfg)):
         g = _rng(seed, prefix)
         fan_in = int(np.prod(shape[1:]))
         if kind.startswith("conv_bn"):
             std = math.sqrt(2.0 / fan_in)
-            if prefix == "backbone.stem.conv1":
+            if prefix.endswith("stem.conv1"):
                 std /= 50.0      # inputs are mean-subtracted 0-255 pixels (std ~50): bring the stem output to O(1)
             sd[prefix + ".weight"] = (g.standard_normal(shape) * std).astype(np.float32)
             c = shape[0]
@@ -153,7 +200,7 @@ def _base_state_dict(cfg, seed):
             sd[prefix + ".norm.running_var"] = g.uniform(0.5, 1.5, c).astype(np.float32)
             sd[prefix + ".norm.num_batches_tracked"] = np.asarray(0, dtype=np.int64)
         elif kind.startswith("conv_bias"):
-            gain = {"conv_bias": math.sqrt(2.0), "conv_bias_obj": 4.0, "conv_bias_delta": 0.35}[kind]
+            gain = {"conv_bias": math.sqrt(2.0), "conv_bias_obj": 4.0, "conv_bias_delta": 0.35, "conv_bias_lin": 1.0}[kind]
             sd[prefix + ".weight"] = (g.standard_normal(shape) * gain / math.sqrt(fan_in)).astype(np.float32)
             sd[prefix + ".bias"] = (g.standard_normal(shape[0]) * 0.05).astype(np.float32)
         elif kind == "embedding":
@@ -162,9 +209,14 @@ def _base_state_dict(cfg, seed):
             gain = {"fc_cls": 4.0, "fc_box": 0.5, "fc": math.sqrt(2.0)}[kind]
             sd[prefix + ".weight"] = (g.standard_normal(shape) * gain / math.sqrt(fan_in)).astype(np.float32)
             sd[prefix + ".bias"] = (g.standard_normal(shape[0]) * 0.05).astype(np.float32)
-        if prefix == "backbone.res4.%d.conv3" % (BLOCKS_PER_STAGE[cfg.RESNETS.DEPTH][2] - 1):
+        if not fpn and prefix == "backbone.res4.%d.conv3" % (BLOCKS_PER_STAGE[cfg.RESNETS.DEPTH][2] - 1):
             sd["proposal_generator.anchor_generator.cell_anchors.0"] = cell_anchors(
                 cfg.ANCHOR_GENERATOR.SIZES[0], cfg.ANCHOR_GENERATOR.ASPECT_RATIOS[0])
+        if fpn and prefix == "backbone.fpn_output5":
+            ratios = cfg.ANCHOR_GENERATOR.ASPECT_RATIOS
+            for li, sizes in enumerate(cfg.ANCHOR_GENERATOR.SIZES):
+                sd[f"proposal_generator.anchor_generator.cell_anchors.{li}"] = cell_anchors(
+                    sizes, ratios[li] if len(ratios) > 1 else ratios[0])
     return sd
 
 
