@@ -79,7 +79,10 @@ def test_fpn_detector_oracle_and_weights():
     from oracle.fpn_oracle import FPNDetectorOracle
     from vltk_amd.config import fpn_config, is_fpn, vg_c4_config
     from vltk_amd.weights import make_state_dict, synthetic_images
-    cfg = fpn_config(depth=50, post_nms_topk=40, pre_nms_topk=200, detections=6)
+    # anchors twice the usual size: with random weights the top proposals all come from P2 / P3, whose boxes must reach the
+    # second pooling level (sqrt(area) >= 112, frcnn.py:444-460) for the level loop to be exercised
+    cfg = fpn_config(depth=50, post_nms_topk=200, pre_nms_topk=200, detections=6,
+                     overrides=[("anchor_generator", "sizes", [[64], [128], [256], [512], [1024]])])
     assert is_fpn(cfg) and not is_fpn(vg_c4_config())
     sd = make_state_dict(cfg, seed=3)
     assert sd["roi_heads.box_head.fc1.weight"].shape == (1024, 256 * 7 * 7)

@@ -23,7 +23,9 @@ def nchw(t):
 
 
 def build(precision, depth=50, seed=3, **kw):
-    cfg = fpn_config(depth=depth, post_nms_topk=60, pre_nms_topk=300, detections=10, **kw)
+    # anchors twice the usual size so that P3's proposals reach the second pooling level (see tests/test_fpn_oracle.py)
+    cfg = fpn_config(depth=depth, post_nms_topk=200, pre_nms_topk=300, detections=10,
+                     overrides=[("anchor_generator", "sizes", [[64], [128], [256], [512], [1024]])], **kw)
     sd = make_state_dict(cfg, seed=seed)
     m = FRCNN(cfg, precision=precision).load_state_dict(sd).eval()
     assert isinstance(m, FRCNNFPN)
