@@ -44,6 +44,24 @@ KERNEL_NAMES = {   # kernel_timing() bucket -> (rocprofv3 kernel name, descripti
 }
 
 
+def fpn_gflop_per_image(R, H=800, W=1333):
+    """Algorithmic 2*MAC of the ResNet-101-FPN detector per image, by stage (analytic; bottom-up res2-res4 from SURVEY.md 8d)."""
+    def ceil2(v):
+        return (v + 1) // 2
+    h, w = ceil2(ceil2(H)), ceil2(ceil2(W))                 # stride 4 (pad-1 max-pool)
+    px = []                                                 # pixels of C2..C5 = P2..P5
+    for _ in range(4):
+        px.append(h * w)
+        h, w = ceil2(h), ceil2(w)
+    res5 = px[3] * 2 * (512 * 1024 + 9 * 512 * 512 + 512 * 2048 + 1024 * 2048 + 2 * (2048 * 512 + 9 * 512 * 512 + 512 * 2048)) / 1e9
+    neck = sum(p * 2 * (c * 256 + 9 * 256 * 256) for p, c in zip(px, (256, 512, 1024, 2048))) / 1e9
+    rpn_px = sum(px) + h * w                                # + P6 (every second pixel of P5)
+    rpn = rpn_px * 2 * (9 * 256 * 256 + 256 * 15) / 1e9
+    box = R * 2 * (12544 * 1024 + 1024 * 1024) / 1e9
+    pred = R * 2 * (1024 * 1601 + 1152 * 256 + 256 * 401 + 4 * 1024) / 1e9
+    return {"backbone": 292.4 + res5, "neck": neck, "rpn_head": rpn, "box_head": box, "predictor_outputs": pred}
+
+
 def stage_fractions(st, B, R, arch):
     """Per stage of the forward: ms, algorithmic TFLOP/s and fraction of the f16 MFMA peak (backbone and whole
     model are asked for separately); the index stages (proposals, outputs) are latency-bound: ms only."""
@@ -168,15 +186,19 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--proposals", type=int, default=300, help="RPN.POST_NMS_TOPK_TEST (RoIs through the Res5 head)")
+    ap.add_argument("--proposals", type=int, default=None,
+                    help="RPN.POST_NMS_TOPK_TEST = RoIs through the box head (default 300; 1000 for r101-fpn)")
     ap.add_argument("--detections", type=int, default=100)
     ap.add_argument("--head-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--arch", default="r101", choices=["r101", "x152"],
-                    help="r101 = the BASELINE workload (configs[1]); x152 = ResNeXt-152 32x8d (SURVEY.md 8d config c4, extra)")
+    ap.add_argument("--arch", default="r101", choices=["r101", "x152", "r101-fpn"],
+                    help="r101 = the BASELINE workload (configs[1], C4: the model the reference has); x152 = ResNeXt-152 32x8d C4 "
+                         "(SURVEY.md 8d config c4, extra); r101-fpn = the FPN detector (build extension, UNPINNED vs the reference, extra)")
     ap.add_argument("--selftest-launch", default=None, choices=["ok", "fail"],
                     help="CPU check of the rank launcher only: gloo ranks, no GPU, no model (tests/test_bench_launcher.py)")
     a = ap.parse_args()
+    if a.proposals is None:
+        a.proposals = 1000 if a.arch == "r101-fpn" else 300
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     if a.selftest_launch:
@@ -213,10 +235,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
+    from vltk_amd import FRCNN, fpn_config, make_state_dict, synthetic_images, vg_c4_config
     from vltk_amd.parallel import gather_outputs_async
     arch = dict(depth=152, num_groups=32, width_per_group=8) if a.arch == "x152" else {}
-    cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}", **arch)
+    if a.arch == "r101-fpn":
+        cfg = fpn_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}")
+    else:
+        cfg = vg_c4_config(post_nms_topk=a.proposals, detections=a.detections, device=f"cuda:{local_rank}", **arch)
     sd = make_state_dict(cfg, seed=1234)
     model = FRCNN(cfg, precision="fp16", device=f"cuda:{local_rank}").load_state_dict(sd).eval()
     if a.head_chunk >= 0:
@@ -298,7 +323,38 @@ def main():
     st = model.stage_timing_ms()                 # HIP events of the LAST step's stages (backbone / RPN head / proposals / RoI heads / outputs)
     assert out["roi_features"].shape[0] == world * B
 
-    if rank == 0:
+    if rank == 0 and a.arch == "r101-fpn":
+        # the FPN detector is composed on the host from stage-level C-ABI calls: stage timers only (no per-kernel buckets)
+        gf = fpn_gflop_per_image(a.proposals)
+        tot = sum(gf.values())
+        stages = {}
+        for k, ms in st.items():
+            e = {"ms": round(float(ms), 3)}
+            if k in gf and ms > 0:
+                e["tflops"] = round(gf[k] * B / ms, 1)
+                e["frac_of_mfma_peak"] = round(gf[k] * B / ms / PEAK_F16_TFLOPS, 4)
+            stages[k] = e
+        ach = tot * world * B * a.steps / dt / 1e3
+        line = {
+            "metric": "images/sec FRCNN feature extraction, 800x1333 batch",
+            "value": round(world * B * a.steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "ms_per_step_with_timers": round(dt_timers / a.steps * 1e3, 3), "n_ranks_seen": n_ranks_seen,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "EXTRA, UNPINNED vs the reference (it has no FPN model, SURVEY.md D1): ResNet-101-FPN Faster R-CNN fp16 "
+                                   f"(detectron2 layout: FPN neck, RPN over P2-P6, RoIAlign 7x7, 2-FC box head), {B} synthetic 800x1333 "
+                                   f"images per GPU per step, R={a.proposals} proposals, max {a.detections} detections/img, seeded synthetic weights",
+                       "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
+            "roofline": {"bound": "mfma", "achieved": round(ach / world, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / world / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole forward (algorithmic conv / GEMM flops of the model over the step time; this path has stage "
+                                   "timers only)",
+                         "alg_gflop_per_image": {k: round(v, 1) for k, v in dict(gf, total=tot).items()},
+                         "stages_last_step": stages},
+        }
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    elif rank == 0:
         # res3 / res4 run as two half-batches on two streams: those launches overlap in time (their summed durations are
         # not wall time), so they are reported apart and the per-kernel figures cover the launches that ran alone
         conc = kt.pop("two_stream_backbone")
