@@ -122,6 +122,38 @@ def test_grouped_conv(case, dt):
     assert G.rel_err(y, ref) <= (1e-3 if dt == L.VK_F16 else 2e-5)
 
 
+BLK_CASES = [
+    # name, N,H,W, channels, groups, dil: what conv3x3_blk.hip takes (64-channel slabs of 2-D tiles, weights in registers)
+    ("dense64_ragged", 3, 37, 70, 64, 1, 1),        # res2 conv2 of ResNet-50/101: tiles of 8 x 32 with ragged right / bottom edges
+    ("dense64_tiny", 1, 5, 9, 64, 1, 1),            # an image smaller than one tile
+    ("g8_multi_tile", 2, 41, 67, 256, 32, 1),       # 8 channels per group, several tiles per slab and per workgroup
+    ("g16", 2, 19, 33, 512, 32, 1),
+    ("g32", 3, 50, 84, 1024, 32, 1),                # res4 of ResNeXt-152 32x8d at its real map size
+    ("g64_roi", 37, 14, 14, 2048, 32, 2),           # Res5 head: one tile per RoI, dilation 2, ragged last pixel block
+    ("g32_roi", 5, 14, 14, 128, 4, 2),
+]
+
+
+@pytest.mark.parametrize("case", BLK_CASES, ids=[c[0] for c in BLK_CASES])
+def test_conv3x3_blk_kernel(case, monkeypatch):
+    """conv3x3_blk.hip against the fp32 reference AND bit-for-bit against the im2col kernel it replaces (same K order; the
+    products it skips are with structurally-zero weights)."""
+    _, N, H, W, c, groups, dil = case
+    g = _rng(zlib.crc32(case[0].encode()))
+    x = torch.from_numpy(g.standard_normal((N, c, H, W)).astype(np.float32))
+    w = (g.standard_normal((c, c // groups, 3, 3)) * (2.0 / (c // groups * 9)) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, c), g.standard_normal(c) * 0.1, g.standard_normal(c) * 0.1, g.uniform(0.5, 1.5, c))
+    ys = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("VK_CONV3X3_BLK", on)
+        ys.append(G.conv2d(x, w, bn=bn, stride=1, pad=dil, dil=dil, relu=(c != 128), dt=L.VK_F16, groups=groups))
+    assert torch.equal(ys[0], ys[1])
+    wf, bf = G.fold_ref(w, bn, L.VK_F16)
+    ref = F.conv2d(x.half().float(), wf, None, 1, dil, dil, groups) + bf.view(1, -1, 1, 1)
+    ref = (F.relu(ref) if c != 128 else ref).half().float()
+    assert G.rel_err(ys[0], ref) <= 1e-3
+
+
 @pytest.mark.parametrize("M,c1,c2,cout,res", [(1500, 64, 64, 256, False), (4000, 512, 1024, 512, False),
                                               (130, 128, 256, 256, True), (2600, 128, 192, 256, True)])
 def test_conv1x1_dual(M, c1, c2, cout, res):

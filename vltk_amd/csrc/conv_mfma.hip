@@ -379,6 +379,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
                    "conv: the dual-source form is 1x1, stride 1, f16, Cout %% 256 == 0, Cin and Cin2 multiples of 32");
         return launch_conv_duo(a, stream);
     }
+    if (conv3x3_blk_eligible(a)) return launch_conv3x3_blk(a, stream);
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
         if (conv_strip_eligible(a)) return launch_conv_strip(a, stream);

@@ -81,6 +81,8 @@ bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (1x1 convs: 128x256 tile, two workgroups per CU)
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
+bool conv3x3_blk_eligible(const ConvArgs &a);             // conv3x3_blk.hip (narrow channel blocks: ResNeXt grouped 3x3, dense 64 -> 64)
+int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
 bool conv_strip_eligible(const ConvArgs &a);              // conv_strip.hip (1x1, Cin 256/512: LDS-resident pixel panel, all output channels per workgroup)
 int launch_conv_strip(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
