@@ -40,13 +40,58 @@ LAYERS = [
 ]
 
 
+# ResNeXt-152 32x8d grouped conv2 layers (batch 16, as bench.py --arch x152): name: (N, H, W, C, groups, dil, count)
+X152_GROUPED = [
+    ("x152.res2.conv2", 16, 200, 333, 256, 32, 1, 3),
+    ("x152.res3.conv2", 16, 100, 167, 512, 32, 1, 8),
+    ("x152.res4.conv2", 16, 50, 84, 1024, 32, 1, 36),
+    ("x152.res5.conv2", 4800, 14, 14, 2048, 32, 2, 3),
+]
+
+
+def grouped(a):
+    g = np.random.Generator(np.random.PCG64(1))
+    tot = 0.0
+    for name, N, H, W, C_, groups, dil, count in X152_GROUPED:
+        if a.names and name not in a.names:
+            continue
+        cg = C_ // groups
+        w = (g.standard_normal((C_, cg, 3, 3)) * (2.0 / (cg * 9)) ** 0.5).astype(np.float32)
+        wd, bd = G.pack_conv(w, None, np.zeros(C_, np.float32), L.VK_F16, groups)
+        x = torch.randn((N, H, W, C_), device=G.DEV).half()
+        y = torch.empty_like(x)
+
+        def run():
+            L.call("vk_conv2d", G.P(x), N, H, W, C_, G.P(wd), G.P(bd), None, G.P(y), C_, C_, 3, 3, 1, dil, dil, groups, 1,
+                   L.VK_F16, L.VK_F16, G.stream())
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        M = N * H * W
+        flop, byts = 2.0 * M * C_ * 9 * cg, 2.0 * M * C_ * 2
+        tot += ms * count
+        print(f"{name:18s} x{count:2d}  M={M:8d} C={C_:5d} cg={cg:3d}  {ms * 1e3:8.1f} us  {flop / ms / 1e9:7.1f} TFLOP/s  {byts / ms / 1e6:7.1f} GB/s(alg)"
+              f"   floors: mfma {flop / (PEAK_TF * 1e9) * 1e3:7.1f} us, hbm {byts / (HBM_TBS * 1e9) * 1e3:7.1f} us", flush=True)
+    print(f"grouped 3x3 layers of one x152 forward (batch 16, R = 300): {tot:.2f} ms")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--json", default=None)
     ap.add_argument("names", nargs="*")
+    ap.add_argument("--x152", action="store_true", help="the grouped conv2 layers of ResNeXt-152 32x8d instead")
     a = ap.parse_args()
+    if a.x152:
+        return grouped(a)
     g = np.random.Generator(np.random.PCG64(0))
     N = a.batch
     rows, tot = [], {"ms": 0.0, "mfma_ms": 0.0, "hbm_ms": 0.0, "floor_ms": 0.0, "gflop": 0.0}

@@ -14,10 +14,10 @@
 //   * only the MFMAs of the diagonal blocks are issued (32-wide blocks: half of them), the products with the
 //     structurally-zero weights are skipped -- they are exact zeros, so the result is bit-identical to the im2col kernel's
 //     (same K order: tap-major, 32 channels per step);
-//   * two workgroups per CU (<= 44 KiB LDS, <= 256 VGPRs): one loads its next tile while the other multiplies.
+//   * one 512-thread workgroup per CU; the NEXT tile arrives by LDS-DMA in a second LDS buffer while this one is multiplied.
 // Tile shapes: 8 x 32 output pixels (dilation 1, any image size) for the backbone; the whole 14 x 14 RoI with dilation 2
-// for the Res5 head (:1344-1355).  LDS image: [padded pixel][8 x 16-B chunks], chunk' = chunk ^ key with
-// key = (col + (TW mod 8) * row) & 7: conflict-free ds_read_b128 for the 16x16x32 operand lane map.
+// for the Res5 head (:1344-1355), run as rows of 16 with 14 valid columns.  LDS image: [padded pixel][8 x 16-B chunks],
+// chunk' = chunk ^ (padded column & 7): conflict-free ds_read_b128 for the 16x16x32 operand lane map.
 // Weights are read in the layout vk_pack_conv_weight already produces ([cout][9 taps][64-channel slice], zero outside a
 // channel's group), so nothing about the packing or the ABI changes.
 #include "vk_common.h"
@@ -38,21 +38,39 @@ struct BlkK {
     int wrow_bytes;          // 9 * 64 * 2
     int relu;
     int tiles_x, tiles_y, ntiles;
+    const char *zero;        // >= 16 zero bytes: source of the out-of-image pixels
 };
 
-template <int CB, int TH, int TW, int DIL>
-__global__ __launch_bounds__(256, 2) void conv3x3_blk_kernel(BlkK p) {
-    extern __shared__ __attribute__((aligned(16))) char tile[];
+#define VKB_GLDS16(gptr, lptr)                                                                         \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void blk_vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One 512-thread workgroup per CU (two waves per SIMD).  The tile of step t+1 is brought into the other LDS buffer by
+// LDS-DMA (no registers) while the waves multiply tile t: per wave NQ DMA instructions of 1 KiB = 8 padded pixels x 128 B,
+// the XOR swizzle applied on the per-lane SOURCE address (the LDS image of a DMA is lane-linear), out-of-image pixels
+// fetched from a zero page.  One counted vmcnt + one raw barrier hands a buffer over; a second barrier frees it.
+// TW: tile width, a multiple of 16 (a 16-pixel MFMA column block never wraps a tile row, so a lane's LDS addresses are
+// `per-lane constant + per-block scalar`); VW <= TW: columns that exist (the 14 x 14 RoI runs as TW = 16, VW = 14).
+template <int CB, int TH, int TW, int VW, int DIL>
+__global__ __launch_bounds__(512, 2) void conv3x3_blk_kernel(BlkK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(TW % 16 == 0 && VW <= TW, "tile width");
     constexpr int PH = TH + 2 * DIL, PW = TW + 2 * DIL;
-    constexpr int NPX = TH * TW, NPB = (NPX + 15) / 16;
+    constexpr int CBL = TW / 16;                // column blocks per tile row
+    constexpr int NPB = TH * CBL;               // 16-pixel blocks per tile
     constexpr int KS = CB / 32;                 // 32-channel MFMA steps per tap
-    constexpr int KEYM = TW & 7;
-    constexpr int NLD = (PH * PW * 8 + 255) / 256;
+    constexpr int NQ = ((PH * PW + 7) / 8 + 7) / 8;   // DMA instructions per wave and tile
+    constexpr int BUF = NQ * 8 * 1024;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cp = wave & 1;                    // which 32 output channels of the slab this wave produces
-    const int par = wave >> 1;                  // which pixel blocks (even / odd)
+    const int par = wave >> 1;                  // which pixel blocks: par, par + 4, ...
     const int g = lane >> 4, j = lane & 15;
     const int slab = blockIdx.y;
     const int cbase = (CB == 32) ? cp * 32 : 0; // first input channel (within the slab) of this wave's block
@@ -70,66 +88,107 @@ __global__ __launch_bounds__(256, 2) void conv3x3_blk_kernel(BlkK p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) wf[ni][tap][ks] = *reinterpret_cast<const half8 *>(wr + (tap * 64 + ks * 32) * 2);
     }
-    float b[8];
-    {
-        const float *bp = p.bias + slab * 64 + cp * 32 + g * 8;
+    // the slab's 64 biases sit behind the two tile buffers (read back per block: 8 VGPRs the fragment sets need)
+    float *bias_lds = reinterpret_cast<float *>(smem + 2 * BUF);
+    if (tid < 64) bias_lds[tid] = p.bias[slab * 64 + tid];
+    const float *bl = bias_lds + cp * 32 + g * 8;
+    // LDS byte offset of this lane's fragment for tap column dx and step ks, relative to the block's first pixel of
+    // the tap row: pixel (j + dx * DIL) * 128 B + swizzled 16-B chunk (the key is the padded column mod 8; 16-pixel
+    // blocks keep it independent of the block)
+    // (step ks = 1 reads chunk + 4: the same offset with bit 6 flipped, all bases being multiples of 128)
+    int colb[3];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) b[e] = bp[e];
+    for (int dx = 0; dx < 3; ++dx) {
+        const int pc = j + dx * DIL;
+        colb[dx] = pc * 128 + (((cbase / 8 + g) ^ (pc & 7)) << 4);
     }
-    const int chunk0 = cbase / 8 + g;           // + ks * 4
+    blk_vm_wait<0>();                           // the weights are in: from here on vmcnt counts DMA pieces and stores only
+    __syncthreads();                            // ... and the biases are in LDS
 
-    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
-        const int n = t / (p.tiles_x * p.tiles_y);
-        const int tr = t - n * (p.tiles_x * p.tiles_y);
+    // DMA geometry of this lane: instruction q of the wave covers padded pixels (wave * NQ + q) * 8 + (lane >> 3).  What
+    // does not depend on the tile is computed once (the padded (row, column) of the first piece; the others follow by
+    // adding 8 columns with at most two row wraps); offsets inside an image are 32-bit.
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int P0 = wave * NQ * 8 + (lane >> 3);
+    const int pr0 = P0 / PW, pc0 = P0 - pr0 * PW;   // piece q: 8 q pixels further along the padded rows
+    auto request = [&](int t, int buf) {
+        const int n = t / tpi;
+        const int tr = t - n * tpi;
         const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
-        const int y0 = ty * TH, x0 = tx * TW;
-        const char *img = p.x + (long)n * p.H * p.W * p.cbytes + slab * 128;
-
-        // ---- tile + halo -> LDS (zero outside the image) ----
-        u32x4 v[NLD];
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int P = idx >> 3, c = idx & 7;
-            const int pr = P / PW, pc = P - pr * PW;
-            const int yy = y0 - DIL + pr, xx = x0 - DIL + pc;
-            const bool ok = idx < PH * PW * 8 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            v[i] = ok ? *reinterpret_cast<const u32x4 *>(img + ((long)yy * p.W + xx) * p.cbytes + c * 16) : u32x4{0u, 0u, 0u, 0u};
+        const int y0 = ty * TH - DIL, x0 = tx * VW - DIL;
+        // first padded pixel of the tile (may lie outside the image: only in-image lanes dereference it)
+        const char *org = p.x + ((long)n * p.H * p.W + (long)y0 * p.W + x0) * p.cbytes + slab * 128;
+        const unsigned nrow = (unsigned)p.H, ncol = (unsigned)p.W;
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < NQ; ++q) {
+            static_assert(8 * (NQ - 1) <= 2 * PW, "a piece is at most two row wraps from the first");
+            int pr = pr0, pc = pc0 + 8 * q;
+            if (pc >= PW) pc -= PW, ++pr;
+            if (pc >= PW) pc -= PW, ++pr;
+            const bool ok = P0 + 8 * q < PH * PW && (unsigned)(y0 + pr) < nrow && (unsigned)(x0 + pc) < ncol;
+            const char *src = ok ? org + ((pr * p.W + pc) * p.cbytes + (((lane & 7) ^ (pc & 7)) << 4)) : p.zero;
+            VKB_GLDS16(src, smem + buf * BUF + (wave * NQ + q) * 1024);
+            __builtin_amdgcn_sched_barrier(0);          // one piece's address at a time (registers)
         }
-        __syncthreads();                        // the previous tile's reads are done
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int P = idx >> 3, c = idx & 7;
-            const int pr = P / PW, pc = P - pr * PW;
-            if (idx < PH * PW * 8) *reinterpret_cast<u32x4 *>(tile + P * 128 + ((c ^ ((pc + KEYM * pr) & 7)) << 4)) = v[i];
-        }
-        __syncthreads();
+    };
 
-        // ---- 16 pixels x 32 channels per step: 9 taps x KS steps, two row tiles ----
-        for (int pb = par; pb < NPB; pb += 2) {
-            const int pi = pb * 16 + j;
-            const int pv = pi < NPX ? pi : NPX - 1;
-            const int r = pv / TW, c = pv - r * TW;
-            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int t = blockIdx.x;
+    if (t < p.ntiles) request(t, 0);
+    int it = 0;
+    for (; t < p.ntiles; t += gridDim.x, ++it) {
+        const int tn = t + gridDim.x;
+        const char *tile = smem + (it & 1) * BUF;
+        if (tn < p.ntiles) {
+            request(tn, (it + 1) & 1);
+            blk_vm_wait<NQ>();                  // all but the NQ pieces just issued: tile t has landed, older stores are done
+        } else {
+            blk_vm_wait<0>();
+        }
+        __builtin_amdgcn_s_barrier();           // every wave's pieces of tile t are in LDS
+
+        const int n = t / tpi;
+        const int tr = t - n * tpi;
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int y0 = ty * TH, x0 = tx * VW;
+        // ---- 16 pixels x 32 channels per block: 9 taps x KS steps, two row tiles.  A wave's blocks are pb = par + 4 i.
+        // Fragment reads run one tap row (3 * KS fragments) AHEAD of the MFMAs in two alternating register sets, across
+        // block boundaries too, so the LDS latency sits under the previous row's MFMAs ----
+        half8 xa[3 * KS], xb[3 * KS];
+        floatx4 acc0, acc1;
+        // block i exists for every wave when 4 i + 3 < NPB (a compile-time fact: no branch, so hipcc keeps COUNTED lgkmcnt
+        // waits across the straight-line code), otherwise only for the waves with par + 4 i < NPB
+        auto exists = [&](int i) { return 4 * i + 3 < NPB || par + 4 * i < NPB; };
+        auto rd = [&](half8 (&x)[3 * KS], int i, int dy) {
+            const int pb = par + 4 * i;
+            if (4 * i >= NPB) return;
+            if (!exists(i)) return;                                      // wave-uniform
+            const int r = pb / CBL, cb = pb - r * CBL;
+            const char *rowp = tile + (r * PW + cb * 16) * 128 + dy * DIL * PW * 128;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int pr = r + (tap / 3) * DIL, pc = c + (tap % 3) * DIL;
-                const char *src = tile + (pr * PW + pc) * 128;
-                const int key = (pc + KEYM * pr) & 7;
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) x[dx * KS + ks] = *reinterpret_cast<const half8 *>(rowp + (colb[dx] ^ (ks * 64)));
+        };
+        auto mm = [&](const half8 (&x)[3 * KS], int dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const half8 xf = *reinterpret_cast<const half8 *>(src + (((chunk0 + ks * 4) ^ key) << 4));
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][tap][ks], xf, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][tap][ks], xf, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][dy * 3 + dx][ks], x[dx * KS + ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][dy * 3 + dx][ks], x[dx * KS + ks], acc1, 0, 0, 0);
                 }
-            }
+        };
+        auto out = [&](int i) {
+            const int pb = par + 4 * i;
+            const int r = pb / CBL, cb = pb - r * CBL;
+            const int c = cb * 16 + j;
             const int oy = y0 + r, ox = x0 + c;
-            if (pi < NPX && oy < p.H && ox < p.W) {
+            if (c < VW && oy < p.H && ox < p.W) {
                 half8 o;
+                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bl), b1 = *reinterpret_cast<const floatx4 *>(bl + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float a0 = acc0[e] + b[e], a1 = acc1[e] + b[4 + e];
+                    float a0 = acc0[e] + b0[e], a1 = acc1[e] + b1[e];
                     if (p.relu) {
                         a0 = a0 > 0.f ? a0 : 0.f;
                         a1 = a1 > 0.f ? a1 : 0.f;
@@ -139,7 +198,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_blk_kernel(BlkK p) {
                 }
                 *reinterpret_cast<half8 *>(p.y + (((long)n * p.H + oy) * p.W + ox) * p.cbytes + slab * 128 + (cp * 32 + g * 8) * 2) = o;
             }
-        }
+        };
+        // block i with row 0 already in X: rows 1, 2 and the next block's row 0 are requested before rows 0, 1, 2 are multiplied
+#define VKB_BLOCK(X, Y, i)                                  \
+    if (exists(i)) {                                        \
+        acc0 = floatx4{0.f, 0.f, 0.f, 0.f};                 \
+        acc1 = floatx4{0.f, 0.f, 0.f, 0.f};                 \
+        rd(Y, i, 1);                                        \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        mm(X, 0);                                           \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        rd(X, i, 2);                                        \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        mm(Y, 1);                                           \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        rd(Y, (i) + 1, 0);                                  \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        mm(X, 2);                                           \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        out(i);                                             \
+    }
+        static_assert(NPB <= 16, "a wave walks at most four pixel blocks per tile");
+        rd(xa, 0, 0);
+        VKB_BLOCK(xa, xb, 0)
+        VKB_BLOCK(xb, xa, 1)
+        VKB_BLOCK(xa, xb, 2)
+        VKB_BLOCK(xb, xa, 3)
+#undef VKB_BLOCK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // every wave is done reading this buffer: the step after next may refill it
     }
 }
 
@@ -167,12 +254,17 @@ static int blk_variant(const ConvArgs &a) {
 
 bool conv3x3_blk_eligible(const ConvArgs &a) { return blk_variant(a) != 0; }
 
-template <int CB, int TH, int TW, int DIL>
+template <int CB, int TH, int TW, int VW, int DIL>
 static int launch_blk(const ConvArgs &a, hipStream_t stream) {
-    constexpr int smem = (TH + 2 * DIL) * (TW + 2 * DIL) * 128;
+    constexpr int smem = 2 * ((((TH + 2 * DIL) * (TW + 2 * DIL) + 7) / 8 + 7) / 8) * 8 * 1024 + 256;
+    static char *zero_page = nullptr;
+    if (!zero_page) {
+        VK_CHECK_HIP(hipMalloc((void **)&zero_page, 256));
+        VK_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_blk_kernel<CB, TH, TW, DIL>),
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_blk_kernel<CB, TH, TW, VW, DIL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
@@ -187,14 +279,16 @@ static int launch_blk(const ConvArgs &a, hipStream_t stream) {
     k.cbytes = a.Cin * 2;
     k.wrow_bytes = 9 * 64 * 2;
     k.relu = a.relu;
-    k.tiles_x = ceil_div(a.W, TW);
+    k.tiles_x = ceil_div(a.W, VW);
     k.tiles_y = ceil_div(a.H, TH);
     const long nt = (long)a.N * k.tiles_x * k.tiles_y;
     VK_REQUIRE(nt > 0 && nt < (1L << 31), VK_EINVAL, "conv3x3_blk: %ld tiles", nt);
     k.ntiles = (int)nt;
+    k.zero = zero_page;
+    VK_REQUIRE((long)(a.H + 8) * a.W * a.Cin * 2 < (1L << 31), VK_EINVAL, "conv3x3_blk: image too large for 32-bit in-image offsets");
     const int slabs = a.Cin / 64;
-    // two workgroups per CU over all slabs; a workgroup keeps its slab's weights in registers across its tiles
-    int gx = 512 / slabs;
+    // one workgroup per CU over all slabs; a workgroup keeps its slab's weights in registers across its tiles
+    int gx = 256 / slabs;
     if (gx < 1) gx = 1;
     if (gx > k.ntiles) gx = k.ntiles;
     const int cg = a.groups > 1 ? a.Cin / a.groups : a.Cin;
@@ -206,7 +300,7 @@ static int launch_blk(const ConvArgs &a, hipStream_t stream) {
         e1 = tm->get();
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL((conv3x3_blk_kernel<CB, TH, TW, DIL>), dim3(gx, slabs), dim3(256), smem, stream, k);
+    hipLaunchKernelGGL((conv3x3_blk_kernel<CB, TH, TW, VW, DIL>), dim3(gx, slabs), dim3(512), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
@@ -218,10 +312,10 @@ static int launch_blk(const ConvArgs &a, hipStream_t stream) {
 
 int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream) {
     switch (blk_variant(a)) {
-        case 1: return launch_blk<32, 8, 32, 1>(a, stream);
-        case 2: return launch_blk<64, 8, 32, 1>(a, stream);
-        case 3: return launch_blk<32, 14, 14, 2>(a, stream);
-        case 4: return launch_blk<64, 14, 14, 2>(a, stream);
+        case 1: return launch_blk<32, 8, 32, 32, 1>(a, stream);
+        case 2: return launch_blk<64, 8, 32, 32, 1>(a, stream);
+        case 3: return launch_blk<32, 14, 16, 14, 2>(a, stream);
+        case 4: return launch_blk<64, 14, 16, 14, 2>(a, stream);
     }
     set_error("conv3x3_blk: shape not eligible");
     return VK_EINVAL;
