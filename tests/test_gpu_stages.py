@@ -267,36 +267,6 @@ def test_conv_1x1_kernels_bit_identical(monkeypatch):
     assert torch.equal(ys[0], ys[1])
 
 
-@pytest.mark.parametrize("cin,cout,res", [(512, 2048, True), (256, 1024, True), (512, 512, False)])
-def test_conv_strip_kernel_bit_identical(cin, cout, res, monkeypatch):
-    """The experimental strip kernel (LDS-resident pixel panel, VK_CONV_STRIP=1) against the two-per-CU kernel on the same
-    1x1 layer, with a ragged last tile: identical bits."""
-    N, H, W = 9, 14, 15                              # M = 1890: 14 full tiles + 98 rows
-    g = np.random.Generator(np.random.PCG64(3))
-    w = (g.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).astype(np.float32)
-    bias = g.standard_normal(cout).astype(np.float32)
-    wd, bd = G.pack_conv(w, None, bias, L.VK_F16)
-    x = torch.randn((N, H, W, cin), device=G.DEV).half()
-    r = torch.randn((N, H, W, cout), device=G.DEV).half() if res else None
-    outs = []
-    for strip in ("0", "1"):
-        monkeypatch.setenv("VK_CONV_STRIP", strip)
-        monkeypatch.setenv("VK_CONV_DUO", "1")
-        y = torch.full((N, H, W, cout), float("nan"), dtype=torch.float16, device=G.DEV)
-        L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(r), G.P(y), cout, cout, 1, 1, 1, 0, 1, 1, 1,
-               L.VK_F16, L.VK_F16, G.stream())
-        torch.cuda.synchronize()
-        outs.append(y)
-    assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0], outs[1])
-    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), torch.from_numpy(w).to(G.DEV).half().float(),
-                                     torch.from_numpy(bias).to(G.DEV)).permute(0, 2, 3, 1)
-    if res:
-        ref = ref + r.float()
-    ref = torch.relu(ref)
-    assert G.rel_err(outs[1].float().cpu(), ref.cpu()) <= 2e-3
-
-
 def test_conv_bias_f32_out():
     """fp16 operands, fp32 output with bias and a channel count that is not a multiple of 8 (RPN heads: 75)."""
     g = _rng(7)

@@ -20,7 +20,7 @@ import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "vltk_amd", "csrc")
-DEFAULT = ["conv_mfma256.hip", "conv_mfma_duo.hip", "conv3x3_panel.hip", "conv_strip.hip"]
+DEFAULT = ["conv_mfma256.hip", "conv_mfma_duo.hip", "conv3x3_panel.hip"]
 
 
 def _regs(tok):

@@ -382,7 +382,6 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (conv3x3_blk_eligible(a)) return launch_conv3x3_blk(a, stream);
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
-        if (conv_strip_eligible(a)) return launch_conv_strip(a, stream);
         if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
         if (conv256_eligible(a)) return launch_conv256(a, stream);
     }

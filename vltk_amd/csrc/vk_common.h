@@ -83,8 +83,6 @@ bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
 bool conv3x3_blk_eligible(const ConvArgs &a);             // conv3x3_blk.hip (narrow channel blocks: ResNeXt grouped 3x3, dense 64 -> 64)
 int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
-bool conv_strip_eligible(const ConvArgs &a);              // conv_strip.hip (1x1, Cin 256/512: LDS-resident pixel panel, all output channels per workgroup)
-int launch_conv_strip(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
 bool conv_duo_pool_ok(const ConvArgs &a);                 // fused-mean form (pool_part set)
 size_t conv_duo_pool_part_bytes(long M, int Cout);
