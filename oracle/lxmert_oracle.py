@@ -54,7 +54,9 @@ class LxmertOracle:
         s = torch.matmul(qh, kh.transpose(-1, -2)) / math.sqrt(d)
         if mask is not None:
             s = s + mask
-        o = torch.matmul(F.softmax(s, dim=-1), vh)
+        # the HIP path's 16-bit attention (csrc/lxmert.hip attention_mfma_kernel) keeps scores and soft-max in fp32 and rounds
+        # the probabilities to the storage type before the second product, as the reference's own bf16 matmul sees them
+        o = torch.matmul(self.q(F.softmax(s, dim=-1)), vh)
         return self.q(o.permute(0, 2, 1, 3).reshape(B, Lq, H))
 
     def att_block(self, x, ctx, mask, p_att, p_out):  # attention + LxmertAttentionOutput :276-280

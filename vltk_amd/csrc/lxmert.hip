@@ -6,7 +6,8 @@
 //
 //   layernorm_kernel   y = scale * LayerNorm(x) (+ y)      one wave per row
 //   embed_ln_kernel    LayerNorm(word[id] + position[l] + token_type[tt])
-//   attention_kernel   softmax(Q K^T / sqrt(d) + mask) V per (batch, head); K and V of one head live in LDS
+//   attention_kernel   softmax(Q K^T / sqrt(d) + mask) V per (batch, head); K and V of one head live in LDS (fp32: strict mode)
+//   attention_mfma_kernel  the same on v_mfma_f32_16x16x32 (bf16 / f16), one wave per (batch, head)
 #include "vk_common.h"
 
 namespace vk {
@@ -207,6 +208,156 @@ __global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ q,
     }
 }
 
+// ---- the same attention on the matrix cores (bf16 / f16, head dim 32 or 64, Lq <= 48, Lk <= 64: LXMERT runs 20 text
+// and 36 visual tokens) ----
+// One WAVE per (batch, head), four per workgroup.  S = Q K^T and O = P V are v_mfma_f32_16x16x32 tiles:
+//   * Q and K rows are the A / B operand fragments as they lie in memory (8 consecutive head-dim elements per lane):
+//     no staging at all for the first product;
+//   * a score tile leaves a lane with S[q = 4g + e][key = j]: the soft-max over the keys of a row reduces over the
+//     key blocks in registers and over the 16 lanes of a group with four shuffles; fp32 throughout;
+//   * P (rounded to the storage type, as the reference's own bf16 matmul sees it) and V^T go through a per-wave LDS
+//     image to become the second product's operands; padded keys carry P = 0 and V = 0.
+typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_b8 __attribute__((ext_vector_type(8)));
+typedef float att_f4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct AttFrag;
+template <>
+struct AttFrag<_Float16> {
+    typedef att_h8 type;
+    static __device__ __forceinline__ att_f4 mma(att_h8 a, att_h8 b, att_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct AttFrag<__bf16> {
+    typedef att_b8 type;
+    static __device__ __forceinline__ att_f4 mma(att_b8 a, att_b8 b, att_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int ATT_MAXQB = 3, ATT_MAXKB = 4;     // 48 queries, 64 keys
+constexpr int ATT_PP = 72;                      // row pitch (elements) of the P and V^T images: 64 keys + 8 (bank skew)
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const T *__restrict__ q, int ldq, const T *__restrict__ k, int ldk,
+                                                            const T *__restrict__ v, int ldv, const float *__restrict__ mask,
+                                                            T *__restrict__ out, int ldo, int heads, int Lq, int Lk, int total,
+                                                            float scale) {
+    typedef typename AttFrag<T>::type frag;
+    constexpr int KD = D / 32, NDB = D / 16;
+    __shared__ __attribute__((aligned(16))) T lds[4][(48 + D) * ATT_PP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int pair = blockIdx.x * 4 + wave;
+    const bool live = pair < total;
+    const int pc = live ? pair : total - 1;             // idle waves redo the last pair (no early exit before the barrier)
+    const int b = pc / heads, h = pc - b * heads;
+    const int QB = (Lq + 15) >> 4, KB = (Lk + 15) >> 4, KS2 = (Lk + 31) >> 5;
+    T *pt = lds[wave], *vt = pt + 48 * ATT_PP;
+    const frag zf = {};
+
+    // ---- operand fragments straight from memory ----
+    frag qf[ATT_MAXQB][KD], kf[ATT_MAXKB][KD];
+#pragma unroll
+    for (int qb = 0; qb < ATT_MAXQB; ++qb) {
+        const int r = qb * 16 + j;
+        const bool ok = qb < QB && r < Lq;
+        const T *src = q + ((long)b * Lq + (ok ? r : 0)) * ldq + h * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const frag t = *reinterpret_cast<const frag *>(src + ks * 32);
+            qf[qb][ks] = ok ? t : zf;
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < ATT_MAXKB; ++kb) {
+        const int r = kb * 16 + j;
+        const bool ok = kb < KB && r < Lk;
+        const T *src = k + ((long)b * Lk + (ok ? r : 0)) * ldk + h * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            const frag t = *reinterpret_cast<const frag *>(src + ks * 32);
+            kf[kb][ks] = ok ? t : zf;
+        }
+    }
+    // ---- V^T image: vt[d][key], zero for the padded keys ----
+    {
+        constexpr int CH = D / 8;                        // 16-byte chunks per V row
+        for (int i = lane; i < KS2 * 32 * CH; i += 64) {
+            const int key = i / CH, c = i - key * CH;
+            frag t = zf;
+            if (key < Lk) t = *reinterpret_cast<const frag *>(v + ((long)b * Lk + key) * ldv + h * D + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vt[(c * 8 + e) * ATT_PP + key] = t[e];
+        }
+    }
+    // ---- S = Q K^T * scale + mask ----
+    att_f4 sc[ATT_MAXQB][ATT_MAXKB];
+#pragma unroll
+    for (int qb = 0; qb < ATT_MAXQB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < ATT_MAXKB; ++kb) {
+            att_f4 a = {0.f, 0.f, 0.f, 0.f};
+            if (qb < QB && kb < KB) {
+#pragma unroll
+                for (int ks = 0; ks < KD; ++ks) a = AttFrag<T>::mma(qf[qb][ks], kf[kb][ks], a);
+            }
+            const int key = kb * 16 + j;
+            const float m = key < Lk ? (mask ? mask[(long)b * Lk + key] : 0.f) : -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = key < Lk ? a[e] * scale + m : -INFINITY;
+            sc[qb][kb] = a;
+        }
+    // ---- soft-max over the keys of each row q = qb*16 + 4g + e: registers (kb), then the 16 lanes of the group ----
+#pragma unroll
+    for (int qb = 0; qb < ATT_MAXQB; ++qb) {
+        if (qb >= QB) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float mx = sc[qb][0][e];
+#pragma unroll
+            for (int kb = 1; kb < ATT_MAXKB; ++kb) mx = fmaxf(mx, sc[qb][kb][e]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float den = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < ATT_MAXKB; ++kb) {
+                const float ex = expf(sc[qb][kb][e] - mx);       // padded keys: exp(-inf) = 0
+                sc[qb][kb][e] = ex;
+                den += ex;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+            const float inv = 1.0f / den;
+            const int row = qb * 16 + g * 4 + e;
+#pragma unroll
+            for (int kb = 0; kb < ATT_MAXKB; ++kb) pt[row * ATT_PP + kb * 16 + j] = (T)(sc[qb][kb][e] * inv);
+        }
+    }
+    __syncthreads();
+    // ---- O = P V: A = P rows (keys contiguous), B = V^T rows (keys contiguous) ----
+#pragma unroll
+    for (int qb = 0; qb < ATT_MAXQB; ++qb) {
+        if (qb >= QB) continue;
+        frag pf[2];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) pf[k2] = *reinterpret_cast<const frag *>(pt + (qb * 16 + j) * ATT_PP + k2 * 32 + g * 8);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            att_f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                if (k2 >= KS2) continue;
+                const frag vf = *reinterpret_cast<const frag *>(vt + (db * 16 + j) * ATT_PP + k2 * 32 + g * 8);
+                o = AttFrag<T>::mma(pf[k2], vf, o);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = qb * 16 + g * 4 + e;
+                if (live && row < Lq) out[((long)b * Lq + row) * ldo + h * D + db * 16 + j] = (T)o[e];
+            }
+        }
+    }
+}
+
 template <typename T>
 static int ln_launch(const void *x, int ldx, const float *g, const float *b, void *y, int ldy, int M, int C, float eps, float scale,
                      int accumulate, const int64_t *ids, const int64_t *tts, const void *pos, const void *typ, int L, hipStream_t s) {
@@ -270,8 +421,26 @@ int vk_attention(const void *q, int ldq, const void *k, int ldk, const void *v, 
     VK_REQUIRE(smem <= 160 * 1024, VK_EINVAL,
                "attention: one head's Q, K, V and scores (%zu bytes at Lq=%d Lk=%d d=%d) must fit the 160 KiB LDS", smem, Lq, Lk, d);
     const float scale = 1.0f / sqrtf((float)d);
-    const dim3 grid(B * heads), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // matrix-core form: 16-bit types, head dim 32 / 64, up to 48 queries and 64 keys, 16-byte aligned rows
+    static const bool no_mfma = getenv("VK_ATTENTION_MFMA") && getenv("VK_ATTENTION_MFMA")[0] == '0';     // A/B switch
+    if (!no_mfma && (dt == VK_F16 || dt == VK_BF16) && (d == 32 || d == 64) && Lq <= 48 && Lk <= 64 && ldq % 8 == 0 && ldk % 8 == 0 &&
+        ldv % 8 == 0 && ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0) {
+        const int total = B * heads;
+        const dim3 grid((total + 3) / 4), block(256);
+#define VK_ATTM(T, DD)                                                                                                   \
+    hipLaunchKernelGGL((attention_mfma_kernel<T, DD>), grid, block, 0, s, (const T *)q, ldq, (const T *)k, ldk, (const T *)v, ldv, mask, \
+                       (T *)out, ldo, heads, Lq, Lk, total, scale)
+        if (dt == VK_F16) {
+            if (d == 64) VK_ATTM(_Float16, 64); else VK_ATTM(_Float16, 32);
+        } else {
+            if (d == 64) VK_ATTM(__bf16, 64); else VK_ATTM(__bf16, 32);
+        }
+#undef VK_ATTM
+        VK_CHECK_HIP(hipGetLastError());
+        return VK_OK;
+    }
+    const dim3 grid(B * heads), block(256);
 #define VK_ATT(T)                                                                                                        \
     do {                                                                                                                 \
         static bool attr = false;                                                                                        \
