@@ -308,7 +308,8 @@ class FRCNNOracle:
     # ---- FastRCNNOutputLayers.forward frcnn.py:1726-1740 ----------------
     def predictor(self, feats):
         sd, p = self.sd, "roi_heads.box_predictor."
-        q = _h if self.emulate else (lambda t: t)
+        # the HIP path keeps the predictor in fp32 in both modes (csrc/model.hip vk_handle::pdt): nothing to emulate
+        q = (lambda t: t)
         f = q(feats)
         scores = F.linear(f, q(sd[p + "cls_score.weight"])) + sd[p + "cls_score.bias"]
         deltas = F.linear(f, q(sd[p + "bbox_pred.weight"])) + sd[p + "bbox_pred.bias"]

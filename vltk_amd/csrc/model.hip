@@ -83,6 +83,7 @@ struct ConvLayer {
     void *w = nullptr;       // device, packed
     float *b = nullptr;      // device, [packed_cout]
     int groups = 1;          // conv2 of a ResNeXt bottleneck (frcnn.py:950)
+    int dt = -1;             // storage / arithmetic type of this layer; -1: the model's (vk_handle::dt)
 };
 
 struct Block {
@@ -104,6 +105,10 @@ struct vk_handle {
     vk_config cfg;
     int device = 0;
     vk_dtype dt = VK_F16;
+    // the box predictor (three small GEMMs + the box-delta rows, frcnn.py:1726-1740) runs in fp32 in BOTH modes: its
+    // inputs are the fp32 RoI features, and fp16 weights / inputs alone would put the class and attribute logits at
+    // 1.1e-3 / 2.0e-3 of the fp32 reference (measured) where north_star asks 1e-3; costs ~1 ms per 9600 RoIs
+    vk_dtype pdt = VK_F32;
     bool finalized = false;
     std::vector<std::string> names;                 // expected state-dict tensors (strict load)
     std::map<std::string, HostTensor> host;
@@ -234,10 +239,11 @@ static int finalize_conv(vk_handle *h, ConvLayer &L) {
         if (!t) return VK_EWEIGHTS;
         bias = t->data.data();
     }
-    const size_t wb = vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, L.groups, h->dt);
+    const vk_dtype ldt = L.dt >= 0 ? (vk_dtype)L.dt : h->dt;
+    const size_t wb = vk_packed_weight_bytes(L.cout, L.cin, L.k, L.k, L.groups, ldt);
     std::vector<char> packed(wb);
     std::vector<float> pb(vk_packed_cout(L.cout));
-    VK_TRY(vk_pack_conv_weight(w->data.data(), bnp, bias, L.cout, L.cin, L.k, L.k, L.groups, h->dt, packed.data(), pb.data()));
+    VK_TRY(vk_pack_conv_weight(w->data.data(), bnp, bias, L.cout, L.cin, L.k, L.k, L.groups, ldt, packed.data(), pb.data()));
     VK_TRY(upload(h, packed.data(), wb, &L.w));
     VK_TRY(upload(h, pb.data(), pb.size() * sizeof(float), (void **)&L.b));
     return VK_OK;
@@ -420,9 +426,10 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
     // + one tile: two half-chunks on two streams keep separate partials and each rounds its tile count up
     if (fused_mean_ok(h, p.P)) p.pool_part = (float *)cv.take(conv_duo_pool_part_bytes((long)rows + 128, h->res5_c));
     p.feat = (float *)cv.take((size_t)p.K * h->res5_c * sizeof(float));
-    p.featT = cv.take((size_t)p.K * h->res5_c * es);
-    p.concat = cv.take((size_t)p.K * (h->res5_c + h->emb_dim) * es);
-    p.attr_hid = cv.take((size_t)p.K * (h->res5_c / 4) * es);
+    const size_t pes = dtype_size(h->pdt);
+    p.featT = cv.take((size_t)p.K * h->res5_c * pes);
+    p.concat = cv.take((size_t)p.K * (h->res5_c + h->emb_dim) * pes);
+    p.attr_hid = cv.take((size_t)p.K * (h->res5_c / 4) * pes);
     p.cls_logits = (float *)cv.take((size_t)p.K * ((c.num_classes + 1 + 7) / 8 * 8) * sizeof(float));
     p.attr_logits = (float *)cv.take((size_t)p.K * ((c.num_attrs + 1 + 7) / 8 * 8) * sizeof(float));
     p.obj_prob = (float *)cv.take((size_t)p.K * sizeof(float));
@@ -464,7 +471,7 @@ static int run_conv(vk_handle *h, const ConvLayer &L, const void *x, int N, int 
     a.groups = L.groups;
     a.relu = relu;
     a.stem = 0;
-    a.dt = h->dt;
+    a.dt = L.dt >= 0 ? (vk_dtype)L.dt : h->dt;
     a.out_dt = out_dt;
     if (Ho) *Ho = a.Ho;
     if (Wo) *Wo = a.Wo;
@@ -801,6 +808,7 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     h->cfg = *cfg;
     h->device = device;
     h->dt = (vk_dtype)cfg->precision;
+    if (getenv("VK_PREDICTOR_FP16")) h->pdt = h->dt;            // A/B switch: round 1's 16-bit predictor
     const char *env = getenv("VK_HEAD_CHUNK");
     if (env && atoi(env) > 0) h->head_chunk = atoi(env);
     if (const char *bs = getenv("VK_BACKBONE_STREAMS"))
@@ -949,6 +957,7 @@ int vk_finalize(vk_handle *h) {
             it->second.shape.push_back(1);
             it->second.shape.push_back(1);
         }
+        L->dt = h->pdt;
         VK_TRY(finalize_conv(h, *L));
     }
     {
@@ -958,12 +967,12 @@ int vk_finalize(vk_handle *h) {
         const HostTensor *b = get_t(h, bp + "bbox_pred.bias", {4 * nb});
         const HostTensor *e = get_t(h, bp + "cls_embedding.weight", {C + 1, h->emb_dim});
         if (!w || !b || !e) return VK_EWEIGHTS;
-        std::vector<char> tmp(w->data.size() * dtype_size(h->dt));
-        to_dt(w->data.data(), w->data.size(), h->dt, tmp.data());
+        std::vector<char> tmp(w->data.size() * dtype_size(h->pdt));
+        to_dt(w->data.data(), w->data.size(), h->pdt, tmp.data());
         VK_TRY(upload(h, tmp.data(), tmp.size(), &h->bbox_w));
         VK_TRY(upload(h, b->data.data(), b->data.size() * sizeof(float), (void **)&h->bbox_b));
-        tmp.resize(e->data.size() * dtype_size(h->dt));
-        to_dt(e->data.data(), e->data.size(), h->dt, tmp.data());
+        tmp.resize(e->data.size() * dtype_size(h->pdt));
+        to_dt(e->data.data(), e->data.size(), h->pdt, tmp.data());
         VK_TRY(upload(h, tmp.data(), tmp.size(), &h->emb));
     }
     h->host.clear();
@@ -1243,14 +1252,14 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
     // ---- box predictor (FastRCNNOutputLayers.forward frcnn.py:1726-1740) ----
     const int C = c.num_classes, F = h->res5_c, E = h->emb_dim, AT = c.num_attrs;
     const int ld_cls = (C + 1 + 7) / 8 * 8, ld_attr = (AT + 1 + 7) / 8 * 8;
-    VK_TRY(launch_concat_embed(p.feat, nullptr, nullptr, F, 0, p.K, p.featT, h->dt, s));
+    VK_TRY(launch_concat_embed(p.feat, nullptr, nullptr, F, 0, p.K, p.featT, h->pdt, s));
     VK_TRY(run_conv(h, h->cls_score, p.featT, p.K, 1, 1, nullptr, p.cls_logits, false, VK_F32, ld_cls, s));
     VK_TRY(launch_softmax_argmax(p.cls_logits, ld_cls, p.K, C + 1, C, p.obj_prob, p.obj_cls, p.max_class, s));
-    VK_TRY(launch_concat_embed(p.feat, h->emb, p.max_class, F, E, p.K, p.concat, h->dt, s));
-    VK_TRY(run_conv(h, h->fc_attr, p.concat, p.K, 1, 1, nullptr, p.attr_hid, true, h->dt, 0, s));
+    VK_TRY(launch_concat_embed(p.feat, h->emb, p.max_class, F, E, p.K, p.concat, h->pdt, s));
+    VK_TRY(run_conv(h, h->fc_attr, p.concat, p.K, 1, 1, nullptr, p.attr_hid, true, h->pdt, 0, s));
     VK_TRY(run_conv(h, h->attr_score, p.attr_hid, p.K, 1, 1, nullptr, p.attr_logits, false, VK_F32, ld_attr, s));
     VK_TRY(launch_softmax_argmax(p.attr_logits, ld_attr, p.K, AT, AT, p.attr_prob, p.attr_cls, nullptr, s));
-    VK_TRY(launch_chosen_deltas(p.featT, F, h->bbox_w, h->bbox_b, p.obj_cls, c.cls_agnostic_bbox_reg, F, p.K, p.chosen, h->dt, s));
+    VK_TRY(launch_chosen_deltas(p.featT, F, h->bbox_w, h->bbox_b, p.obj_cls, c.cls_agnostic_bbox_reg, F, p.K, p.chosen, h->pdt, s));
     set_stage(h, "obj_logits", p.cls_logits, VK_F32, {p.K, ld_cls});
     set_stage(h, "attr_logits", p.attr_logits, VK_F32, {p.K, ld_attr});
     set_stage(h, "chosen_deltas", p.chosen, VK_F32, {p.K, 4});

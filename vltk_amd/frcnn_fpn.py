@@ -81,24 +81,25 @@ class _Layer:
 
 
 class _Linear:
-    """nn.Linear (+ ReLU) through the MFMA GEMMs (vk_linear)."""
+    """nn.Linear (+ ReLU) through the MFMA GEMMs (vk_linear); `fp32`: exact-f32 MFMA whatever the model's mode."""
 
-    def __init__(self, model, w, bias):
+    def __init__(self, model, w, bias, fp32=False):
         self.m = model
         w = _np(w)
         self.nout, self.k = w.shape
-        wp, bp = _pack(w, None, bias, model.dt)
+        self.dt, self.tdt = (L.VK_F32, torch.float32) if fp32 else (model.dt, model.tdt)
+        wp, bp = _pack(w, None, bias, self.dt)
         self.w, self.b = torch.from_numpy(wp).to(model.device), torch.from_numpy(bp).to(model.device)
 
     def __call__(self, x, relu=False, out_f32=False):
         m = self.m
         M = x.shape[0]
-        assert x.shape[1] == self.k and x.is_contiguous()
+        assert x.shape[1] == self.k and x.is_contiguous() and x.dtype == self.tdt
         ldy = (self.nout + 7) // 8 * 8
-        y = torch.empty((M, ldy), dtype=torch.float32 if out_f32 else m.tdt, device=m.device)
+        y = torch.empty((M, ldy), dtype=torch.float32 if out_f32 else self.tdt, device=m.device)
         if M:
             L.call("vk_linear", x.data_ptr(), M, self.k, self.w.data_ptr(), self.b.data_ptr(), None, y.data_ptr(), self.nout, ldy,
-                   L.VK_ACT_RELU if relu else L.VK_ACT_NONE, m.dt, L.VK_F32 if out_f32 else m.dt, m._stream())
+                   L.VK_ACT_RELU if relu else L.VK_ACT_NONE, self.dt, L.VK_F32 if out_f32 else self.dt, m._stream())
         return y
 
 
@@ -250,17 +251,17 @@ class FRCNNFPN(FRCNN):
             if i == 0:
                 w = np.ascontiguousarray(w.reshape(w.shape[0], fc, P * P).transpose(0, 2, 1).reshape(w.shape[0], -1))
             self.fcs.append(_Linear(self, w, sd[f"roi_heads.box_head.fc{i + 1}.bias"]))
-        # predictor (FastRCNNOutputLayers frcnn.py:1676-1740)
+        # predictor (FastRCNNOutputLayers frcnn.py:1676-1740): fp32 in both modes, as in the C4 model (csrc/model.hip pdt)
         bp_ = "roi_heads.box_predictor."
-        self.cls_score = _Linear(self, sd[bp_ + "cls_score.weight"], sd[bp_ + "cls_score.bias"])
-        self.bbox_w = torch.from_numpy(_np(sd[bp_ + "bbox_pred.weight"])).to(self.device, self.tdt).contiguous()
+        self.cls_score = _Linear(self, sd[bp_ + "cls_score.weight"], sd[bp_ + "cls_score.bias"], fp32=True)
+        self.bbox_w = torch.from_numpy(_np(sd[bp_ + "bbox_pred.weight"])).to(self.device).contiguous()
         self.bbox_b = torch.from_numpy(_np(sd[bp_ + "bbox_pred.bias"])).to(self.device)
         self.use_attr = bool(cfg.ROI_BOX_HEAD.ATTR)
         if not self.use_attr:
             raise NotImplementedError("ROI_BOX_HEAD.ATTR=false: the reference's Res5ROIHeads unpacks three outputs (frcnn.py:1400)")
-        self.emb = torch.from_numpy(_np(sd[bp_ + "cls_embedding.weight"])).to(self.device, self.tdt).contiguous()
-        self.fc_attr = _Linear(self, sd[bp_ + "fc_attr.weight"], sd[bp_ + "fc_attr.bias"])
-        self.attr_score = _Linear(self, sd[bp_ + "attr_score.weight"], sd[bp_ + "attr_score.bias"])
+        self.emb = torch.from_numpy(_np(sd[bp_ + "cls_embedding.weight"])).to(self.device).contiguous()
+        self.fc_attr = _Linear(self, sd[bp_ + "fc_attr.weight"], sd[bp_ + "fc_attr.bias"], fp32=True)
+        self.attr_score = _Linear(self, sd[bp_ + "attr_score.weight"], sd[bp_ + "attr_score.bias"], fp32=True)
         self._finalized = True
         return self
 
@@ -398,20 +399,18 @@ class FRCNNFPN(FRCNN):
         self._mark(evs)
         # ---- predictor (FastRCNNOutputLayers.forward :1726-1740) ----
         F_, Cn, At, E = feat.shape[1], int(cfg.ROI_HEADS.NUM_CLASSES), int(cfg.ROI_BOX_HEAD.NUM_ATTRS), self.emb.shape[1]
-        featT = torch.empty((K, F_), dtype=self.tdt, device=dev)
-        L.call("vk_concat_embed", feat.data_ptr(), F_, None, 0, None, K, featT.data_ptr(), self.dt, s)
-        cls_logits = self.cls_score(featT, out_f32=True)
+        cls_logits = self.cls_score(feat, out_f32=True)
         obj_prob = torch.empty(K, dtype=torch.float32, device=dev)
         obj_cls = torch.empty(K, dtype=torch.int32, device=dev)
         max_class = torch.empty(K, dtype=torch.int32, device=dev)
         L.call("vk_softmax_argmax", cls_logits.data_ptr(), cls_logits.shape[1], K, Cn + 1, Cn, obj_prob.data_ptr(), obj_cls.data_ptr(),
                max_class.data_ptr(), s)
-        cat = torch.empty((K, F_ + E), dtype=self.tdt, device=dev)
-        L.call("vk_concat_embed", feat.data_ptr(), F_, self.emb.data_ptr(), E, max_class.data_ptr(), K, cat.data_ptr(), self.dt, s)
+        cat = torch.empty((K, F_ + E), dtype=torch.float32, device=dev)
+        L.call("vk_concat_embed", feat.data_ptr(), F_, self.emb.data_ptr(), E, max_class.data_ptr(), K, cat.data_ptr(), L.VK_F32, s)
         attr_logits = self.attr_score(self.fc_attr(cat, relu=True), out_f32=True)
         chosen = torch.empty((K, 4), dtype=torch.float32, device=dev)
-        L.call("vk_chosen_deltas", featT.data_ptr(), F_, self.bbox_w.data_ptr(), self.bbox_b.data_ptr(), obj_cls.data_ptr(),
-               int(bool(cfg.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG)), F_, K, chosen.data_ptr(), self.dt, s)
+        L.call("vk_chosen_deltas", feat.data_ptr(), F_, self.bbox_w.data_ptr(), self.bbox_b.data_ptr(), obj_cls.data_ptr(),
+               int(bool(cfg.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG)), F_, K, chosen.data_ptr(), L.VK_F32, s)
         st["obj_logits"], st["attr_logits"], st["chosen_deltas"] = cls_logits, attr_logits, chosen
         # ---- outputs (ROIOutputs.inference :1262-1294) ----
         ro = self.roi_outputs
