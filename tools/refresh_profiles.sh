@@ -17,7 +17,16 @@ echo "pmc fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc/w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pmc_w.log 2>&1
 echo "pmc write done"
 find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
-python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_traffic.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
+# HBM bytes per launch of the three kernels with the most GPU time (launches that run alone: the half-batch launches of the
+# two-stream backbone section carry other template arguments)
+python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_duo.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/${TAG}_pmc "conv3x3_panel_kernel<3, 0, 0>" --json $OUT/${TAG}_pmc_panel.json --name conv3x3_panel_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_mfma256_kernel<0>" --json $OUT/${TAG}_pmc_ring.json --name conv_mfma256_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
+python - <<PY
+import json
+ks = [json.load(open("$OUT/${TAG}_pmc_%s.json" % k)) for k in ("duo", "panel", "ring")]
+json.dump({"batch": 32, "proposals": 300, "kernels": ks}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
+PY
 # keep only the summaries (the raw traces are large)
 rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc
 tail -3 $OUT/${TAG}_pmc_summary.txt
