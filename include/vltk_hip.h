@@ -175,9 +175,10 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
  *           overlap each other in time, so their summed durations exceed the wall time they took -- kept apart so that the
  *           buckets above hold only launches that had the GPU to themselves
  * bucket 7: conv3x3_blk_kernel (3x3 over narrow channel blocks: ResNeXt grouped conv2, dense 64 -> 64)
- * launches[8], ms[8], flops[8] (algorithmic 2*M*Cout*K of the launches), bytes[8] (algorithmic HBM bytes:
+ * bucket 8: conv_ws_kernel (1x1, K <= 512, weight-stationary: a workgroup keeps its 256 x K weights in registers)
+ * launches[9], ms[9], flops[9] (algorithmic 2*M*Cout*K of the launches), bytes[9] (algorithmic HBM bytes:
  * input + output (+ residual) + weights, each once). */
-#define VK_NUM_KERNEL_BUCKETS 8
+#define VK_NUM_KERNEL_BUCKETS 9
 int vk_enable_kernel_timing(vk_handle *h, int enable);
 int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 

@@ -267,6 +267,30 @@ def test_conv_1x1_kernels_bit_identical(monkeypatch):
     assert torch.equal(ys[0], ys[1])
 
 
+@pytest.mark.parametrize("M_hw,cin,cout,res", [((7, 50, 84), 256, 1024, True), ((200, 14, 14), 512, 2048, True), ((3, 37, 41), 128, 512, True),
+                                               ((200, 14, 14), 512, 512, False), ((1, 32, 33), 512, 256, True)])
+def test_conv_ws_kernel_bit_identical(M_hw, cin, cout, res, monkeypatch):
+    """conv_ws.hip (weight-stationary 1x1, K <= 512: weights in registers, pixels through an LDS-DMA ring that runs across
+    tile boundaries) against the two-per-CU kernel on the same layer: bit-identical (same K order, same epilogue
+    arithmetic), with many tiles per workgroup, a ragged last tile and every stage count (2 / 4 / 8 per tile)."""
+    N, H, W = M_hw
+    g = _rng(cin * cout + N)
+    x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = (g.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    r = torch.from_numpy(g.standard_normal((N, cout, H, W)).astype(np.float32)) if res else None
+    ys = []
+    for ws in ("1", "0", "1"):
+        monkeypatch.setenv("VK_CONV_WS", ws)
+        ys.append(G.conv2d(x, w, bn=bn, residual_nchw=r, relu=True, dt=L.VK_F16))
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    wf, bf = G.fold_ref(w, bn, L.VK_F16)
+    ref = F.conv2d(x.half().float(), wf) + bf.view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.half().float()
+    assert G.rel_err(ys[0], F.relu(ref).half().float()) <= 1e-3
+
+
 def test_conv_bias_f32_out():
     """fp16 operands, fp32 output with bias and a channel count that is not a multiple of 8 (RPN heads: 75)."""
     g = _rng(7)

@@ -382,6 +382,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (conv3x3_blk_eligible(a)) return launch_conv3x3_blk(a, stream);
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
+        if (conv_ws_eligible(a)) return launch_conv_ws(a, stream);
         if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
         if (conv256_eligible(a)) return launch_conv256(a, stream);
     }

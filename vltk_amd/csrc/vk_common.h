@@ -81,6 +81,8 @@ bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (1x1 convs: 128x256 tile, two workgroups per CU)
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
+bool conv_ws_eligible(const ConvArgs &a);                 // conv_ws.hip (1x1, K <= 512: weight-stationary, weights in registers)
+int launch_conv_ws(const ConvArgs &a, hipStream_t stream);
 bool conv3x3_blk_eligible(const ConvArgs &a);             // conv3x3_blk.hip (narrow channel blocks: ResNeXt grouped 3x3, dense 64 -> 64)
 int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
