@@ -183,10 +183,12 @@ def test_conv1x1_dual(M, c1, c2, cout, res):
     assert G.rel_err(y.float().cpu(), ref) <= 1e-3
 
 
-@pytest.mark.parametrize("N,HW,cin,cout", [(7, 196, 128, 256), (23, 196, 512, 512), (3, 255, 64, 256), (1, 128, 64, 256)])
-def test_conv1x1_meanpool(N, HW, cin, cout):
+@pytest.mark.parametrize("N,HW,cin,cout", [(7, 196, 128, 256), (23, 196, 512, 512), (3, 255, 64, 256), (1, 128, 64, 256),
+                                           (301, 196, 512, 2048), (40, 100, 256, 1024)])
+def test_conv1x1_meanpool(N, HW, cin, cout, monkeypatch):
     """Last Res5 conv3 + residual + ReLU with `.mean(dim=[2,3])` (frcnn.py:1401) folded into the epilogue: equal to
-    conv -> f16 -> mean, and bit-reproducible."""
+    conv -> f16 -> mean, bit-reproducible, and the same bits from the weight-stationary kernel (64-row tiles) and the
+    two-per-CU kernel (128-row tiles): the per-image sums are exact integers."""
     g = _rng(N * HW)
     M = N * HW
     x = torch.from_numpy(g.standard_normal((M, cin)).astype(np.float32)).half()
@@ -204,6 +206,13 @@ def test_conv1x1_meanpool(N, HW, cin, cout):
         torch.cuda.synchronize()
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])
+    monkeypatch.setenv("VK_CONV_WS", "0")
+    ws = torch.empty(nb, dtype=torch.uint8, device=G.DEV)
+    out = torch.empty((N, cout), dtype=torch.float32, device=G.DEV)
+    L.call("vk_conv1x1_meanpool", G.P(xd), N, HW, cin, G.P(wp), G.P(bp), G.P(rd), cout, 1, G.P(out), G.P(ws), nb, G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], out.cpu())
+    monkeypatch.delenv("VK_CONV_WS")
     wf, bf = G.fold_ref(w, bn, L.VK_F16)
     y = F.relu(x.float() @ wf.view(cout, cin).t() + bf + r.float()).half().float()
     ref = y.view(N, HW, cout).mean(dim=1)
