@@ -369,7 +369,6 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     const bool grouped = a.groups > 1;
-    if (a.pool_part && conv_ws_eligible(a)) return launch_conv_ws(a, stream);
     if (a.pool_part) {
         VK_REQUIRE(conv_duo_pool_ok(a) && (!a.x2 || conv_duo_dual_ok(a)), VK_EINVAL,
                    "conv: the fused-mean form is 1x1, stride 1, f16, Cout %% 256 == 0, Ho*Wo >= 128");

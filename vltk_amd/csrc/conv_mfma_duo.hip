@@ -516,20 +516,19 @@ bool conv_duo_pool_ok(const ConvArgs &a) {
            (long)a.N * a.H * a.W * a.Cin * 2 < (1L << 32);
 }
 
-// sized for the finer of the two tilings that write partial sums (64 rows: conv_ws.hip; 128 rows: this kernel)
-size_t conv_duo_pool_part_bytes(long M, int Cout) { return (size_t)((M + 63) / 64) * 2 * Cout * 2 * sizeof(int); }
+size_t conv_duo_pool_part_bytes(long M, int Cout) { return (size_t)((M + D_BM - 1) / D_BM) * 2 * Cout * 2 * sizeof(int); }
 
 // out[n][c] = (exact sum of the tile partials that hold rows of image n) / HoWo, rounded once
-__global__ void pool_finish_kernel(const int *__restrict__ part, int HoWo, int Cout, float *__restrict__ out, int BM) {
+__global__ void pool_finish_kernel(const int *__restrict__ part, int HoWo, int Cout, float *__restrict__ out) {
     const int n = blockIdx.x;
     const long r0 = (long)n * HoWo, r1 = r0 + HoWo - 1;
-    const int t0 = (int)(r0 / BM), t1 = (int)(r1 / BM);
+    const int t0 = (int)(r0 / D_BM), t1 = (int)(r1 / D_BM);
     for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
         long hi = 0;
         unsigned long lo = 0;
         bool bad = false;
         for (int t = t0; t <= t1; ++t) {
-            const int sg = n - (int)((long)t * BM / HoWo);        // 0: the tile's first image, 1: its second
+            const int sg = n - (int)((long)t * D_BM / HoWo);      // 0: the tile's first image, 1: its second
             const int *q = part + (((long)t * 2 + sg) * Cout + c) * 2;
             bad |= q[0] == 0x7fffffff;
             hi += q[0];
@@ -540,8 +539,8 @@ __global__ void pool_finish_kernel(const int *__restrict__ part, int HoWo, int C
     }
 }
 
-int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream, int tile_rows) {
-    hipLaunchKernelGGL(pool_finish_kernel, dim3(N), dim3(256), 0, stream, (const int *)part, HoWo, Cout, out, tile_rows);
+int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(N), dim3(256), 0, stream, (const int *)part, HoWo, Cout, out);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }

@@ -36,8 +36,6 @@ struct WsK {
     int ldy;                 // = Cout
     int relu;
     int m_tiles, n_tiles;
-    int *pool_part;          // fused spatial mean (see conv_mfma_duo.hip): per 64-row tile, (first / second image) x channel x (hi, lo)
-    int HoWo;                // rows per image (pool_part only)
 };
 
 #define VKW_GLDS16(gptr, lptr)                                                                         \
@@ -56,10 +54,7 @@ constexpr int WS_SLOT = WS_BM * 256;         // 64 rows x 128 channels x 2 B
 
 // KC = K / 32 MFMA steps (4, 8, 16)
 // DBG: timing-only ablation builds (VK_WS_DBG, WRONG results): 1 no epilogue, 2 no MFMA, 4 no pixel DMA, 8 no residual DMA
-// POOL: the last Res5 conv3 with `.mean(dim=[2,3])` (frcnn.py:1401) folded in: no output is written; the f16 values a
-// separate mean kernel would read back are summed per image EXACTLY (integer parts and 2^24-scaled fractions, as the
-// two-per-CU kernel does), so the result does not depend on which kernel or tile size produced the partial sums.
-template <int KC, int DBG = 0, bool POOL = false>
+template <int KC, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void conv_ws_kernel(WsK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPT = KC / 4;              // ring stages (128 channels) per tile
@@ -203,81 +198,16 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(WsK p) {
                 else
                     ws_vm_wait<0>();
             }
-            if constexpr (!POOL) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) unit(it, u);
-            } else {
-                const int m_split = (m0 / p.HoWo + 1) * p.HoWo;            // first row of the tile's second image
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {                       // four channels of a lane at a time (registers)
-                    const int qn = q4 >> 1, hh = q4 & 1;
-                    const int ch = wave * 64 + qn * 32 + g * 8 + hh * 4;
-                    const floatx4 bb = *reinterpret_cast<const floatx4 *>(bias_lds + ch);
-                    int ph[2][4];
-                    unsigned pl[2][4], bad = 0;
-#pragma unroll
-                    for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) ph[sg][e] = 0, pl[sg][e] = 0u;
-#pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) {
-                        const int row = pt * 16 + j, m = m0 + row;
-                        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                        half4 rr = {0, 0, 0, 0};
-                        if (p.res) rr = *reinterpret_cast<const half4 *>(res_lds + row * 128 + (((qn * 4 + g) ^ (row & 7)) << 4) + hh * 8);
-                        const bool second = m >= m_split;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x = (acc[pt][2 * qn + hh][e] + bb[e]) + (float)rr[e];
-                            if (p.relu) x = x > 0.f ? x : 0.f;
-                            const float v = (float)(_Float16)x;
-                            const float fl = __builtin_floorf(v);
-                            const int hi = m < p.M ? (int)fl : 0;
-                            const unsigned lo = m < p.M ? (unsigned)((v - fl) * 16777216.0f) : 0u;
-                            ph[0][e] += second ? 0 : hi;
-                            ph[1][e] += second ? hi : 0;
-                            pl[0][e] += second ? 0u : lo;
-                            pl[1][e] += second ? lo : 0u;
-                            if (m < p.M) bad |= (__builtin_fabsf(v) <= 65504.0f ? 0u : 1u) << ((second ? 4 : 0) + e);
-                        }
-                    }
-                    // the 16 lanes of a group hold the 16 rows of each pixel tile: integer sums over them (exact, any order)
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                        for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                ph[sg][e] += __shfl_xor(ph[sg][e], o, 64);
-                                pl[sg][e] += (unsigned)__shfl_xor((int)pl[sg][e], o, 64);
-                            }
-                        bad |= (unsigned)__shfl_xor((int)bad, o, 64);
-                    }
-                    if (j == 0) {
-                        const long tile_id = first + (long)it * ML;
-#pragma unroll
-                        for (int sg = 0; sg < 2; ++sg) {
-                            int *dst = p.pool_part + ((tile_id * 2 + sg) * p.ldy + n0 + ch) * 2;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                dst[2 * e] = ((bad >> (sg * 4 + e)) & 1u) ? 0x7fffffff : ph[sg][e];
-                                dst[2 * e + 1] = (int)pl[sg][e];
-                            }
-                        }
-                    }
-                }
-            }
+            for (int u = 0; u < 8; ++u) unit(it, u);
         }
     }
 }
 
-int conv_pool_tile_rows(const ConvArgs &a) { return conv_ws_eligible(a) ? WS_BM : 128; }
-
 bool conv_ws_eligible(const ConvArgs &a) {
     const char *v = getenv("VK_CONV_WS");                // "0" disables (A/B switch and bit-identity tests; re-read per call)
     if (v && v[0] == '0') return false;
-    if (a.stem || a.x2 || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
-    if (a.pool_part && (a.Ho * a.Wo < WS_BM || a.Ho * a.Wo > 255)) return false;    // a 64-row tile spans at most two images; 2^24-scaled fraction sums < 2^32
+    if (a.stem || a.x2 || a.pool_part || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || (a.Cin != 128 && a.Cin != 256 && a.Cin != 512)) return false;
     const int nt = a.Cout / 256;
@@ -286,15 +216,15 @@ bool conv_ws_eligible(const ConvArgs &a) {
     return M >= 8 * 128 && M < (1L << 31) - 128;      // (a.Cin % 128 == 0: whole 128-channel ring stages)
 }
 
-template <int KC, int DBG = 0, bool POOL = false>
+template <int KC, int DBG = 0>
 static int launch_ws(const WsK &k, hipStream_t stream) {
     constexpr int smem = WS_NS * WS_SLOT + 4 * WS_BM * 128 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, DBG, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_ws_kernel<KC, DBG, POOL>), dim3(256), dim3(256), smem, stream, k);
+    hipLaunchKernelGGL((conv_ws_kernel<KC, DBG>), dim3(256), dim3(256), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
@@ -313,8 +243,6 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     k.relu = a.relu;
     k.m_tiles = (int)((M + WS_BM - 1) / WS_BM);
     k.n_tiles = a.Cout / 256;
-    k.pool_part = (int *)a.pool_part;
-    k.HoWo = a.Ho * a.Wo;
 
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -324,13 +252,6 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     int st;
-    if (a.pool_part) {
-        switch (a.Cin) {
-            case 128: st = launch_ws<4, 0, true>(k, stream); break;
-            case 256: st = launch_ws<8, 0, true>(k, stream); break;
-            default: st = launch_ws<16, 0, true>(k, stream); break;
-        }
-    } else
     switch (a.Cin) {
         case 128: st = launch_ws<4>(k, stream); break;
         case 256: st = launch_ws<8>(k, stream); break;
@@ -353,7 +274,7 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         tm->recs.push_back({a.concurrent ? 6 : 8, 2.0 * (double)M * a.Cout * a.Cin, e0, e1, (int)M, a.Cout, a.Cin, 1, 1,
-                            2.0 * ((double)M * a.Cin + (double)M * a.Cout * ((a.res ? 1 : 0) + (a.pool_part ? 0 : 1)) + (double)a.Cout * a.Cin)});
+                            2.0 * ((double)M * a.Cin + (double)M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.Cin)});
     }
     return VK_OK;
 }

@@ -725,7 +725,7 @@ int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_pac
     a.relu = relu;
     a.dt = a.out_dt = VK_F16;
     VK_TRY(launch_conv(a, (hipStream_t)stream));
-    return launch_pool_finish((const float *)workspace, N, HW, cout, out_mean, (hipStream_t)stream, conv_pool_tile_rows(a));
+    return launch_pool_finish((const float *)workspace, N, HW, cout, out_mean, (hipStream_t)stream);
 }
 
 static void stem_geom(int H, int W, int *H1, int *W1, int *Hp, int *Wp) {
@@ -1237,22 +1237,8 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
                 x = a;
                 std::swap(a, b2);
             }
-            if (p.pool_part) {
-                // the partial sums were written per 64- or 128-row tile, by whichever kernel took the last conv3
-                const Block &lb = h->res5.back();
-                ConvArgs pa;
-                memset(&pa, 0, sizeof(pa));
-                pa.N = nb;
-                pa.H = pa.Ho = hh;
-                pa.W = pa.Wo = ww;
-                pa.Cin = lb.conv3.cin;
-                pa.Cout = pa.ldy = lb.conv3.cout;
-                pa.kh = pa.kw = pa.stride = pa.dil = pa.groups = pa.relu = 1;
-                pa.dt = pa.out_dt = h->dt;
-                pa.pool_part = pp;
-                pa.x2 = lb.fused_shortcut ? (const void *)pp : nullptr;
-                VK_TRY(launch_pool_finish(pp, nb, hh * ww, h->res5_c, p.feat + (size_t)(k0 + n0) * h->res5_c, hs, conv_pool_tile_rows(pa)));
-            }
+            if (p.pool_part)
+                VK_TRY(launch_pool_finish(pp, nb, hh * ww, h->res5_c, p.feat + (size_t)(k0 + n0) * h->res5_c, hs));
         }
         if (split) {
             VK_CHECK_HIP(hipEventRecord(h->ev_join, h->side));

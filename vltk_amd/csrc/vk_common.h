@@ -83,13 +83,12 @@ bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
 bool conv_ws_eligible(const ConvArgs &a);                 // conv_ws.hip (1x1, K <= 512: weight-stationary, weights in registers)
 int launch_conv_ws(const ConvArgs &a, hipStream_t stream);
-int conv_pool_tile_rows(const ConvArgs &a);               // rows per partial-sum tile of the fused-mean form: 64 (conv_ws) or 128 (conv_duo)
 bool conv3x3_blk_eligible(const ConvArgs &a);             // conv3x3_blk.hip (narrow channel blocks: ResNeXt grouped 3x3, dense 64 -> 64)
 int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
 bool conv_duo_pool_ok(const ConvArgs &a);                 // fused-mean form (pool_part set)
 size_t conv_duo_pool_part_bytes(long M, int Cout);
-int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream, int tile_rows = 128);                 // the dual-source form has no other kernel
+int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream);                 // the dual-source form has no other kernel
 
 // optional per-launch event timing (set by vk_forward when enabled; thread-local)
 struct KernelTimer {
