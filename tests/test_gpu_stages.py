@@ -289,10 +289,11 @@ def test_conv_ws_kernel_bit_identical(M_hw, cin, cout, res, monkeypatch):
     bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
     r = torch.from_numpy(g.standard_normal((N, cout, H, W)).astype(np.float32)) if res else None
     ys = []
-    for ws in ("1", "0", "1"):
+    for ws, waves in (("1", "8"), ("0", "8"), ("1", "4"), ("1", "8")):
         monkeypatch.setenv("VK_CONV_WS", ws)
+        monkeypatch.setenv("VK_WS_WAVES", waves)            # two waves per SIMD (the default) / one
         ys.append(G.conv2d(x, w, bn=bn, residual_nchw=r, relu=True, dt=L.VK_F16))
-    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
     wf, bf = G.fold_ref(w, bn, L.VK_F16)
     ref = F.conv2d(x.half().float(), wf) + bf.view(1, -1, 1, 1)
     if res:

@@ -6,24 +6,29 @@
 // the matrix cores and not by HBM.  A 128 x 256 tile of the two-per-CU kernel (conv_mfma_duo.hip) moves, per output element
 // at K = 512, 4 B of pixels + 8 B of WEIGHTS + 4 B of residual / output; the weights are the same 256 x K block for every
 // tile of a column, re-streamed from L2 each time.  Here a workgroup OWNS one 256-channel column block for its whole life:
-//   * its weights (256 x K f16 = 256 KiB at K = 512) are loaded once into REGISTERS -- each of the four waves keeps the
-//     fragments of its 64 channels for every K step (64 x 4 VGPRs) -- so the K loop streams pixels only: 8 B per output
-//     element instead of 16;
+//   * its weights (256 x K f16 = 256 KiB at K = 512) are loaded once into REGISTERS -- each of the eight waves (two per
+//     SIMD, <= 256 registers each) keeps the fragments of its 32 channels for every K step (32 x 4 VGPRs) -- so the K loop
+//     streams pixels only: 8 B per output element instead of 16;
 //   * pixels run through a 6-slot LDS ring of 64 rows x 128 channels (16 KiB) filled by LDS-DMA five stages ahead,
-//     straight across tile boundaries (tiles are 64 rows: 64 accumulator registers beside the 256 of the weights), so the
+//     straight across tile boundaries (tiles are 64 rows: 32 accumulator registers beside the 128 of the weights), so the
 //     next tile's pixels arrive under this tile's epilogue; one counted vmcnt and one raw barrier per stage; the tile's
-//     RESIDUAL rows come by LDS-DMA too (requested when the tile starts, each wave its own 64 channels), so the epilogue
-//     has no load to wait for -- with one wave per SIMD nothing else would cover an HBM latency there;
+//     RESIDUAL rows come by LDS-DMA too (requested when the tile starts, each wave its own channels), so the epilogue
+//     has no load to wait for;
 //   * workgroups that share an XCD (blockIdx mod 8) and an M lane walk the same pixel tiles with different column blocks,
 //     so a pixel tile is fetched from HBM once per XCD L2 and read from L2 by the other column blocks.
 // Same K order and epilogue arithmetic as conv_mfma_duo.hip / conv_mfma256.hip ((acc + bias) + residual, ReLU, round to f16):
 // a layer's bits do not depend on which of the three the dispatcher picks.
 #include "vk_common.h"
 
+#include <cstdio>
+#include <type_traits>
+#include <vector>
+
 namespace vk {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 struct WsK {
     const char *x;
@@ -36,6 +41,7 @@ struct WsK {
     int ldy;                 // = Cout
     int relu;
     int m_tiles, n_tiles;
+    unsigned long *stamps;   // DBG & 32 builds only: 8 cycle sums per wave
 };
 
 #define VKW_GLDS16(gptr, lptr)                                                                         \
@@ -47,17 +53,35 @@ __device__ __forceinline__ void ws_vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int WS_NS = 6;                     // ring slots
-constexpr int WS_D = WS_NS - 1;              // stages the DMA runs ahead
 constexpr int WS_BM = 64;                    // rows per tile
-constexpr int WS_SLOT = WS_BM * 256;         // 64 rows x 128 channels x 2 B
 
 // KC = K / 32 MFMA steps (4, 8, 16)
 // DBG: timing-only ablation builds (VK_WS_DBG, WRONG results): 1 no epilogue, 2 no MFMA, 4 no pixel DMA, 8 no residual DMA
-template <int KC, int DBG = 0>
-__global__ __launch_bounds__(256, 1) void conv_ws_kernel(WsK p) {
+// NW: waves per workgroup.  4 = one wave per SIMD with 64 channels each (256 weight registers); 8 = two waves per SIMD with
+// 32 channels each (128 weight registers, <= 256 registers per lane), so that one wave's barrier / LDS / epilogue latencies
+// are covered by the other wave of the SIMD
+// Tried on top of the two-waves-per-SIMD form and removed (bit-identical, no faster): FREE-RUNNING waves -- no barrier in the
+// loop; a wave announced that ITS pieces of a stage had landed with an LDS atomic add on the stage's arrival counter and
+// started a stage after a bounded spin on that counter, so that it could run up to A stages ahead of the slowest wave
+// (16 KiB stages, 7 slots, A = 1 / 2: 650 / 622 us vs 647 with the barrier on the 512 -> 2048 layer at M = 200 704; 8 KiB
+// stages, 15 slots, A = 4 / 6: 662 / 676 us).  The two waves of a SIMD would have to run a whole TILE apart for one's
+// epilogue to sit under the other's MFMAs, and the ring cannot hold that much (LDS: 64 rows x 512 channels = 64 KiB per tile).
+template <int KC, int NW, int DBG = 0>
+__global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SPT = KC / 4;              // ring stages (128 channels) per tile
+    constexpr int SCH = 128;                 // channels per ring stage
+    constexpr int KSL = SCH / 32;            // MFMA K steps per stage
+    constexpr int PITCH = SCH * 2;           // bytes per pixel row of a stage
+    constexpr int WS_SLOT = WS_BM * PITCH;
+    constexpr int WS_NS = 6;                 // ring slots
+    constexpr int WS_D = 5;                  // stages the DMA runs ahead
+    constexpr int RING = WS_NS * WS_SLOT;
+    constexpr int SPT = KC / KSL;            // ring stages per tile
+    constexpr int NI = 16 / NW;              // 16-channel MFMA row tiles per wave
+    constexpr int WCH = NI * 16;             // channels per wave
+    constexpr int PPW = WS_SLOT / 1024 / NW; // DMA pieces per wave and ring stage
+    constexpr int RPW = 32 / NW;             // residual DMA pieces per wave and tile
+    constexpr int NU = NI * 2;               // epilogue units (32 channels x 16 pixels) per wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,129 +101,216 @@ __global__ __launch_bounds__(256, 1) void conv_ws_kernel(WsK p) {
     // ---- weights of the wave's 64 channels, every K step, in registers ----
     // row j of MFMA row tile ni is channel (ni>>1)*32 + (j>>2)*8 + (ni&1)*4 + (j&3) of the wave's 64: a lane ends up with 8
     // consecutive channels per pair of tiles = one 16-byte store, as in conv_mfma.hip
-    half8 wf[4][KC];
+    half8 wf[NI][KC];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int co = n0 + wave * 64 + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = n0 + wave * WCH + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
         const char *wr = p.w + (long)co * p.kbytes + g * 16;
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) wf[ni][ks] = *reinterpret_cast<const half8 *>(wr + ks * 64);
     }
-    char *res_lds = smem + WS_NS * WS_SLOT + wave * (WS_BM * 128);           // this wave's 64 rows x 64 channels of residual
-    float *bias_lds = reinterpret_cast<float *>(smem + WS_NS * WS_SLOT + 4 * WS_BM * 128);
-    bias_lds[tid] = p.bias[n0 + tid];
+    char *res_lds = smem + RING + wave * (WS_BM * WCH * 2);       // this wave's 64 rows x WCH channels of residual
+    float *bias_lds = reinterpret_cast<float *>(smem + RING + 4 * WS_BM * 128);
+    if (tid < 256) bias_lds[tid] = p.bias[n0 + tid];
     ws_vm_wait<0>();                         // from here on vmcnt counts DMA pieces, residual loads and stores
     __syncthreads();
 
-    // ---- LDS-DMA: piece q of the wave = rows (wave * 4 + q) * 4 + (lane >> 4) of the stage, 16-byte slot lane & 15 of the
+    // ---- LDS-DMA: piece q of the wave = rows (wave * PPW + q) * 4 + (lane >> 4) of the stage, 16-byte slot lane & 15 of the
     // 256-byte row, holding source chunk slot ^ (row & 15) (the swizzle sits on the source address) ----
-    const int drow = lane >> 4;
-    auto request = [&](int q_, int qlo = 0, int qhi = 4) {   // q_ = global stage index of this workgroup; pieces [qlo, qhi)
+    // (64-channel stages: 128-byte rows = whole cache lines, pieces of 8 rows, slot lane & 7 holding chunk slot ^ (row & 7))
+    constexpr int LPR = PITCH / 16;          // lanes (16-byte slots) per row
+    const int drow = lane / LPR, dslot = lane & (LPR - 1);
+    auto request = [&](int q_, int qlo = 0, int qhi = 16 / NW) {   // q_ = global stage index of this workgroup; pieces [qlo, qhi)
         const int it = q_ / SPT, st = q_ - it * SPT;
         const int m0 = (first + it * ML) * WS_BM;
-        char *dst = smem + (q_ % WS_NS) * WS_SLOT + wave * 4 * 1024;
+        char *dst = smem + (q_ % WS_NS) * WS_SLOT + wave * PPW * 1024;
 #pragma unroll
         for (int q = qlo; q < qhi; ++q) {
-            const int row = (wave * 4 + q) * 4 + drow;
+            const int row = (wave * PPW + q) * (64 / LPR) + drow;
             const int m = min(m0 + row, p.M - 1);                             // rows past M are computed and dropped
-            VKW_GLDS16(p.x + (long)m * p.kbytes + st * 256 + (((lane & 15) ^ (row & 15)) << 4), dst + q * 1024);
+            VKW_GLDS16(p.x + (long)m * p.kbytes + st * PITCH + ((dslot ^ (row & (LPR - 1))) << 4), dst + q * 1024);
         }
     };
     for (int q_ = 0; q_ < WS_D && q_ < total; ++q_) request(q_);
 
     // fragment address of pixel tile pt, step ksl of a stage: slot + pt * 4096 + row j * 256 + swizzled chunk
-    int xoff[4];
+    int xoff[KSL];
 #pragma unroll
-    for (int ksl = 0; ksl < 4; ++ksl) xoff[ksl] = j * 256 + (((ksl * 4 + g) ^ j) << 4);
+    for (int ksl = 0; ksl < KSL; ++ksl) xoff[ksl] = j * PITCH + (((ksl * 4 + g) ^ (j & (LPR - 1))) << 4);
 
     // ---- main loop.  The epilogue is cut into 8 units (32 channels x 16 pixels).  (Measured on this kernel: 180 us of
     // epilogue + 320 us of MFMA + 190 us of loop skeleton add up to 698 us on the 512 -> 2048 layer at M = 200 704: with one
     // wave per SIMD the phases do not overlap.  A build with two accumulator sets that issued the previous tile's units
     // between the MFMA groups was correct and no faster (K = 256: 149 vs 136 us), so one set is kept.) ----
-    floatx4 acc[4][4];
-    auto unit = [&](int it_, int u) {                         // unit u = (qn, pt) of tile it_'s epilogue
-        const int qn = u >> 2, pt = u & 3;
-        const int ch = wave * 64 + qn * 32 + g * 8;
-        const int m = (first + it_ * ML) * WS_BM + pt * 16 + j;
-        const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bias_lds + ch), b1 = *reinterpret_cast<const floatx4 *>(bias_lds + ch + 4);
-        const int row = pt * 16 + j;
-        half8 rr = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.res) rr = *reinterpret_cast<const half8 *>(res_lds + row * 128 + (((qn * 4 + g) ^ (row & 7)) << 4));
-        half8 o;
+    unsigned long c_vm4[4] = {0, 0, 0, 0}, c_bar4[4] = {0, 0, 0, 0};
+    unsigned long c_vm = 0, c_bar = 0, c_mma = 0, c_rw = 0, c_epi = 0, c_all = 0, t_a = 0, t_b = 0;   // DBG & 32
+    if constexpr (DBG & 32) c_all = __builtin_amdgcn_s_memtime();
+    floatx4 acc[4][NI];
+    // 64-byte residual rows (NW = 8): chunk c of row r sits at slot c ^ RSW[(r >> 2) & 3], which spreads every 16-lane
+    // group of the ds_read_b128 over all 64 banks
+    auto rsw = [](int r) { return (0x1320 >> (((r >> 2) & 3) * 4)) & 3; };   // {0, 2, 3, 1}
+    // The epilogue of a tile, specialised at compile time on residual / ReLU / "every row of the tile exists" so that it is one
+    // basic block: all residual reads up front, packed fp32 adds, v_cvt_pk_f16_f32, ReLU on the rounded halves (the same
+    // bits as max before rounding), unpredicated stores.  (The first version branched per unit on p.res / p.relu / m < M: every
+    // unit paid a full LDS latency and ~60 VALU instructions -- 465 cycles per unit, 30 % of the kernel.)
+    auto epilogue = [&](int it_, auto res_c, auto relu_c, auto full_c) {
+        constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+        const long mbase = (long)(first + it_ * ML) * WS_BM;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x0 = (acc[pt][2 * qn][e] + b0[e]) + (float)rr[e];
-            float x1 = (acc[pt][2 * qn + 1][e] + b1[e]) + (float)rr[4 + e];
-            if (p.relu) {
-                x0 = x0 > 0.f ? x0 : 0.f;
-                x1 = x1 > 0.f ? x1 : 0.f;
+        for (int u0 = 0; u0 < NU; u0 += 4) {                  // four units (32 channels x 64 pixels) at a time
+            half8 rr[4];
+            if constexpr (RES) {
+#pragma unroll
+                for (int u = u0; u < u0 + 4; ++u) {
+                    const int qn = u >> 2, row = (u & 3) * 16 + j;
+                    if constexpr (NW == 4)
+                        rr[u - u0] = *reinterpret_cast<const half8 *>(res_lds + row * 128 + (((qn * 4 + g) ^ (row & 7)) << 4));
+                    else
+                        rr[u - u0] = *reinterpret_cast<const half8 *>(res_lds + row * 64 + ((g ^ rsw(row)) << 4));
+                }
             }
-            o[e] = (_Float16)x0;
-            o[4 + e] = (_Float16)x1;
+#pragma unroll
+            for (int u = u0; u < u0 + 4; ++u) {               // unit u = (qn, pt): 32 channels x 16 pixels
+                const int qn = u >> 2, pt = u & 3;
+                const int ch = wave * WCH + qn * 32 + g * 8;
+                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bias_lds + ch), b1 = *reinterpret_cast<const floatx4 *>(bias_lds + ch + 4);
+                floatx4 x0 = acc[pt][2 * qn] + b0, x1 = acc[pt][2 * qn + 1] + b1;
+                if constexpr (RES) {
+                    x0 += __builtin_convertvector(__builtin_shufflevector(rr[u - u0], rr[u - u0], 0, 1, 2, 3), floatx4);
+                    x1 += __builtin_convertvector(__builtin_shufflevector(rr[u - u0], rr[u - u0], 4, 5, 6, 7), floatx4);
+                }
+                half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
+                half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                const long m = mbase + pt * 16 + j;
+                if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
+            }
         }
-        if (m < p.M) *reinterpret_cast<half8 *>(p.y + ((long)m * p.ldy + n0 + ch) * 2) = o;
     };
     for (int it = 0; it < ntw; ++it) {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[pt][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-        // residual rows of this tile -> LDS: 8 pieces of 8 rows x 128 B of this wave's 64 channels, 16-byte slot lane & 7 of
-        // a row holding chunk slot ^ (row & 7)
+            for (int ni = 0; ni < NI; ++ni) acc[pt][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // residual rows of this tile -> LDS: NW = 4: 8 pieces of 8 rows x 128 B of this wave's 64 channels, 16-byte slot
+        // lane & 7 of a row holding chunk slot ^ (row & 7); NW = 8: 4 pieces of 16 rows x 64 B, slot lane & 3 holding chunk
+        // slot ^ rsw(row)
         const int m0 = (first + it * ML) * WS_BM;
         if (p.res && !(DBG & 8)) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = q * 8 + (lane >> 3);
-                const int m = min(m0 + row, p.M - 1);
-                VKW_GLDS16(p.res + ((long)m * p.ldy + n0 + wave * 64) * 2 + (((lane & 7) ^ (row & 7)) << 4), res_lds + q * 1024);
+            for (int q = 0; q < RPW; ++q) {
+                if constexpr (NW == 4) {
+                    const int row = q * 8 + (lane >> 3);
+                    const int m = min(m0 + row, p.M - 1);
+                    VKW_GLDS16(p.res + ((long)m * p.ldy + n0 + wave * 64) * 2 + (((lane & 7) ^ (row & 7)) << 4), res_lds + q * 1024);
+                } else {
+                    const int row = q * 16 + (lane >> 2);
+                    const int m = min(m0 + row, p.M - 1);
+                    VKW_GLDS16(p.res + ((long)m * p.ldy + n0 + wave * 32) * 2 + (((lane & 3) ^ rsw(row)) << 4), res_lds + q * 1024);
+                }
             }
         }
 #pragma unroll
         for (int st = 0; st < SPT; ++st) {
             const int gs = it * SPT + st;
+            if constexpr (DBG & 32) t_a = __builtin_amdgcn_s_memtime();
+            // stage gs has landed; the WS_D - 1 later stages stay in flight.  (Also letting the stores / residual requests issued
+            // since stay in flight -- exact counts per stage of the tile -- was measured: no change, so the simple form stays.)
             if (gs + WS_D - 1 < total)
-                ws_vm_wait<4 * (WS_D - 1)>();                // stage gs has landed; the later stages stay in flight
+                ws_vm_wait<PPW * (WS_D - 1)>();
             else
                 ws_vm_wait<0>();
+            if constexpr (DBG & 32) {
+                t_b = __builtin_amdgcn_s_memtime();
+                c_vm += t_b - t_a;
+                c_vm4[st & 3] += t_b - t_a;
+            }
             __builtin_amdgcn_s_barrier();                    // ... for every wave; and stage gs - 1 has been read by all
+            if constexpr (DBG & 32) {
+                t_a = __builtin_amdgcn_s_memtime();
+                c_bar += t_a - t_b;
+                c_bar4[st & 3] += t_a - t_b;
+            }
             const bool more = gs + WS_D < total && !(DBG & 4);   // a stage to request into the slot stage gs - 1 just left
             const char *slot = smem + (gs % WS_NS) * WS_SLOT;
             // all 16 fragments of the stage are requested up front; the four DMA pieces of the stage WS_D ahead are issued
             // BETWEEN the MFMA groups, where their issue cost (~100 cycles each) hides under the matrix pipe
-            half8 xf[4][4];
+            half8 xf[KSL][4];
 #pragma unroll
-            for (int ksl = 0; ksl < 4; ++ksl)
+            for (int ksl = 0; ksl < KSL; ++ksl)
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) xf[ksl][pt] = *reinterpret_cast<const half8 *>(slot + pt * 4096 + xoff[ksl]);
+                for (int pt = 0; pt < 4; ++pt) xf[ksl][pt] = *reinterpret_cast<const half8 *>(slot + pt * 16 * PITCH + xoff[ksl]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ksl = 0; ksl < 4; ++ksl) {
+            for (int ksl = 0; ksl < KSL; ++ksl) {
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) {
+                    for (int ni = 0; ni < NI; ++ni) {
                         if constexpr (DBG & 2) {
                             asm volatile("" ::"v"(xf[ksl][pt]));
                             continue;
                         }
-                        acc[pt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][4 * st + ksl], xf[ksl][pt], acc[pt][ni], 0, 0, 0);
+                        acc[pt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][KSL * st + ksl], xf[ksl][pt], acc[pt][ni], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) request(gs + WS_D, ksl, ksl + 1);
+                if constexpr (NW == 4) {
+                    if (more) request(gs + WS_D, ksl, ksl + 1);
+                } else {
+                    if (more && (ksl & 1)) request(gs + WS_D, ksl >> 1, (ksl >> 1) + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (DBG & 32) c_mma += __builtin_amdgcn_s_memtime() - t_a;
         }
         // ---- epilogue: (acc + bias) + residual, ReLU, f16.  The residual pieces are older than the SPT stages requested since ----
+        if constexpr (DBG & 32) t_a = __builtin_amdgcn_s_memtime();
         if (!(DBG & 1)) {
             if (p.res) {
                 if ((it + 1) * SPT - 1 + WS_D < total)
-                    ws_vm_wait<4 * SPT>();
+                    ws_vm_wait<PPW * SPT>();
                 else
                     ws_vm_wait<0>();
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) unit(it, u);
+            if constexpr (DBG & 32) {
+                t_b = __builtin_amdgcn_s_memtime();
+                c_rw += t_b - t_a;
+            }
+            const bool full = (long)(first + it * ML + 1) * WS_BM <= p.M;
+            auto by_full = [&](auto r, auto l) {
+                if (full)
+                    epilogue(it, r, l, std::true_type{});
+                else
+                    epilogue(it, r, l, std::false_type{});
+            };
+            auto by_relu = [&](auto r) {
+                if (p.relu)
+                    by_full(r, std::true_type{});
+                else
+                    by_full(r, std::false_type{});
+            };
+            if (p.res)
+                by_relu(std::true_type{});
+            else
+                by_relu(std::false_type{});
+            if constexpr (DBG & 32) c_epi += __builtin_amdgcn_s_memtime() - t_b;
+        }
+    }
+    if constexpr (DBG & 32) {
+        if (lane == 0) {
+            unsigned long *o = p.stamps + ((long)blockIdx.x * NW + wave) * 16;
+            o[0] = __builtin_amdgcn_s_memtime() - c_all;
+            o[1] = c_vm;
+            o[2] = c_bar;
+            o[3] = c_mma;
+            o[4] = c_rw;
+            o[5] = c_epi;
+            o[6] = ntw;
+            o[7] = __builtin_amdgcn_s_memrealtime();
+            for (int q = 0; q < 4; ++q) {
+                o[8 + q] = c_vm4[q];
+                o[12 + q] = c_bar4[q];
+            }
         }
     }
 }
@@ -216,15 +327,15 @@ bool conv_ws_eligible(const ConvArgs &a) {
     return M >= 8 * 128 && M < (1L << 31) - 128;      // (a.Cin % 128 == 0: whole 128-channel ring stages)
 }
 
-template <int KC, int DBG = 0>
+template <int KC, int NW = 8, int DBG = 0>
 static int launch_ws(const WsK &k, hipStream_t stream) {
-    constexpr int smem = WS_NS * WS_SLOT + 4 * WS_BM * 128 + 1024;
+    constexpr int smem = 6 * WS_BM * 256 + 4 * WS_BM * 128 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_ws_kernel<KC, DBG>), dim3(256), dim3(256), smem, stream, k);
+    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG>), dim3(256), dim3(NW * 64), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
@@ -243,6 +354,7 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     k.relu = a.relu;
     k.m_tiles = (int)((M + WS_BM - 1) / WS_BM);
     k.n_tiles = a.Cout / 256;
+    k.stamps = nullptr;
 
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -252,23 +364,50 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     int st;
-    switch (a.Cin) {
-        case 128: st = launch_ws<4>(k, stream); break;
-        case 256: st = launch_ws<8>(k, stream); break;
-        default: {
-            const char *d = getenv("VK_WS_DBG");
-            switch (d ? atoi(d) : 0) {
-                case 1: st = launch_ws<16, 1>(k, stream); break;
-                case 2: st = launch_ws<16, 2>(k, stream); break;
-                case 3: st = launch_ws<16, 3>(k, stream); break;
-                case 4: st = launch_ws<16, 4>(k, stream); break;
-                case 8: st = launch_ws<16, 8>(k, stream); break;
-                case 12: st = launch_ws<16, 12>(k, stream); break;
-                case 15: st = launch_ws<16, 15>(k, stream); break;
-                default: st = launch_ws<16>(k, stream); break;
+    const char *nwv = getenv("VK_WS_WAVES");             // "4" / "8": A/B switch, re-read per call
+    const int nw = nwv ? atoi(nwv) : 8;
+    if (const char *sf = getenv("VK_WS_STAMPS")) {       // diagnostic: one stamped launch (K = 512), cycle sums appended to the file
+        if (a.Cin != 512) return VK_EINVAL;
+        const size_t nb = (size_t)256 * 8 * 16 * sizeof(unsigned long);
+        VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
+        VK_CHECK_HIP(hipMemsetAsync(k.stamps, 0, nb, stream));
+        st = nw == 8 ? launch_ws<16, 8, 32>(k, stream) : launch_ws<16, 4, 32>(k, stream);
+        VK_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long> h(256 * 8 * 16);
+        VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
+        VK_CHECK_HIP(hipFree(k.stamps));
+        if (FILE *f = fopen(sf, "a")) {
+            fprintf(f, "# wg wave total vm_wait barrier stage_body res_wait epilogue tiles realtime\n");
+            for (int w = 0; w < 256 * nw; ++w) {
+                fprintf(f, "%d %d", w / nw, w % nw);
+                for (int i = 0; i < 16; ++i) fprintf(f, " %lu", h[(size_t)w * 16 + i]);
+                fprintf(f, "\n");
             }
-            break;
+            fclose(f);
         }
+    } else {
+        const char *d = getenv("VK_WS_DBG");
+        const int dbg = d ? atoi(d) : 0;
+#define VKW_DBG_CASE(NW_, D_) \
+    case D_: st = launch_ws<16, NW_, D_>(k, stream); break;
+        if (a.Cin == 128)
+            st = nw == 8 ? launch_ws<4, 8>(k, stream) : launch_ws<4, 4>(k, stream);
+        else if (a.Cin == 256)
+            st = nw == 8 ? launch_ws<8, 8>(k, stream) : launch_ws<8, 4>(k, stream);
+        else if (nw == 8) {
+            switch (dbg) {
+                VKW_DBG_CASE(8, 1) VKW_DBG_CASE(8, 2) VKW_DBG_CASE(8, 3) VKW_DBG_CASE(8, 4) VKW_DBG_CASE(8, 8) VKW_DBG_CASE(8, 12)
+                VKW_DBG_CASE(8, 15)
+                default: st = launch_ws<16, 8>(k, stream); break;
+            }
+        } else {
+            switch (dbg) {
+                VKW_DBG_CASE(4, 1) VKW_DBG_CASE(4, 2) VKW_DBG_CASE(4, 3) VKW_DBG_CASE(4, 4) VKW_DBG_CASE(4, 8) VKW_DBG_CASE(4, 12)
+                VKW_DBG_CASE(4, 15)
+                default: st = launch_ws<16, 4>(k, stream); break;
+            }
+        }
+#undef VKW_DBG_CASE
     }
     VK_TRY(st);
     if (tm) {
