@@ -271,8 +271,8 @@ def test_chunking_and_determinism(setup):
 
 
 def test_two_stream_backbone_is_bit_identical(setup):
-    """res3/res4 as two half-batches on two HIP streams (the bench-size default) against the single-stream order: every
-    output and the res4 map are bit-identical, for an even and an odd batch."""
+    """res3/res4 as two to four image groups on as many HIP streams (the bench-size default is two) against the single-stream
+    order: every output and the res4 map are bit-identical, for an even and an odd batch."""
     cfg, sd, x, shapes = setup
     m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
     m.set_option("backbone_split_min_batch", 2)
@@ -280,14 +280,14 @@ def test_two_stream_backbone_is_bit_identical(setup):
         xs = torch.cat([x] * reps) if isinstance(reps, int) else torch.cat([x, x, x[:1]])
         sh = torch.tensor(shapes * reps) if isinstance(reps, int) else torch.tensor(shapes + shapes + shapes[:1])
         outs = []
-        for streams in (1, 2, 2):
+        for streams in (1, 2, 3, 4, 2):
             m.set_option("backbone_streams", streams)
             m(xs, sh)
             o = {k: v.clone() for k, v in m.forward_padded().items()}
             o["res4"] = m.get_stage("res4").clone()
             outs.append(o)
         for k in outs[0]:
-            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), k
+            assert all(torch.equal(outs[0][k], o[k]) for o in outs[1:]), k
 
 
 def test_two_stream_head_is_bit_identical(setup):

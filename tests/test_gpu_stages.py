@@ -155,9 +155,11 @@ def test_conv3x3_blk_kernel(case, monkeypatch):
 
 
 @pytest.mark.parametrize("M,c1,c2,cout,res", [(1500, 64, 64, 256, False), (4000, 512, 1024, 512, False),
-                                              (130, 128, 256, 256, True), (2600, 128, 192, 256, True)])
-def test_conv1x1_dual(M, c1, c2, cout, res):
-    """conv3 + stride-1 projection shortcut as one GEMM (`out += shortcut`, frcnn.py:970-977): two inputs, K = c1 + c2."""
+                                              (130, 128, 256, 256, True), (2600, 128, 192, 256, True),
+                                              (2500, 512, 1024, 2048, False), (1030, 256, 768, 256, True)])
+def test_conv1x1_dual(M, c1, c2, cout, res, monkeypatch):
+    """conv3 + stride-1 projection shortcut as one GEMM (`out += shortcut`, frcnn.py:970-977): two inputs, K = c1 + c2.
+    K >= 1024 runs on the 256 x 256 ring kernel, shorter K on the two-per-CU kernel; where both apply they give the same bits."""
     g = _rng(M + c1)
     x1 = torch.from_numpy(g.standard_normal((M, c1)).astype(np.float32)).half()
     x2 = torch.from_numpy(g.standard_normal((M, c2)).astype(np.float32)).half()
@@ -174,6 +176,11 @@ def test_conv1x1_dual(M, c1, c2, cout, res):
     y = torch.empty((M, cout), dtype=torch.float16, device=G.DEV)
     L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y), cout, 1, G.stream())
     torch.cuda.synchronize()
+    monkeypatch.setenv("VK_CONV256_DUAL", "0")              # the two-per-CU kernel on the same layer
+    y_duo = torch.full_like(y, float("nan"))
+    L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y_duo), cout, 1, G.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_duo)
     f1, fb1 = G.fold_ref(w1, bn1, L.VK_F16)
     f2, fb2 = G.fold_ref(w2, bn2, L.VK_F16)
     ref = x1.float() @ f1.view(cout, c1).t() + x2.float() @ f2.view(cout, c2).t() + (fb1 + fb2)

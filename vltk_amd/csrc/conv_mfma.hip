@@ -375,6 +375,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         return launch_conv_duo(a, stream);
     }
     if (a.x2) {
+        if (conv256_dual_ok(a)) return launch_conv256(a, stream);
         VK_REQUIRE(conv_duo_dual_ok(a), VK_EINVAL,
                    "conv: the dual-source form is 1x1, stride 1, f16, Cout %% 256 == 0, Cin and Cin2 multiples of 32");
         return launch_conv_duo(a, stream);

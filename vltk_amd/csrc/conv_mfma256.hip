@@ -36,6 +36,8 @@ struct Conv256K {
     const char *res;
     char *y;
     const char *zero;    // >= 16 B of zeros (source of padded taps / rows beyond M)
+    const char *x2;      // DUAL builds: second K segment of a 1x1 conv (stages >= st_per_tap): rows of [M, cin2]
+    int cin2_bytes;
     int H, W, Ho, Wo, HoWo, M;
     int cin_bytes, ldy;
     int kw, stride, pad, dil;
@@ -60,7 +62,10 @@ constexpr int R_SMEM = R_NSLOT * R_SLOT;     // 128 KiB
 // 16 = taps innermost (no gain), 32 / 64 = weight / pixel DMA pieces all read ONE cached line (timing only),
 // 4 = static s_setprio(1) for waves 4-7 (no effect measured), 8 = WITHOUT the s_setprio pair around each
 // 4-MFMA group (the pair is worth +1.3 % median, interleaved A/B in one process on one device).
-template <int DBG>
+// DUAL: 1x1, stride 1, two inputs: K = Cin | Cin2 (conv3 + projection shortcut as one GEMM, as in conv_mfma_duo.hip -- same
+// K order and epilogue, so the bits are the same; at K = 512 + 1024 the 256 x 256 tile needs a third less operand fill per
+// MFMA than the 128 x 256 one)
+template <int DBG, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     // ---- LDS-DMA source state: this lane feeds rows (wave*2+i)*16 + (lane>>2), i = 0,1 ----
     const int lrow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);   // logical 16-B chunk whose bytes land at phys chunk lane&3
-    long a_off[2];
+    long a_off[2], a_off2[2];
     int bh[2], bw[2];
     const char *wsrc[2];
 #pragma unroll
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
         const int wo = rem - ho * p.Wo;
         const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
         a_off[i] = ((long)(n_img * p.H + h0) * p.W + w0) * p.cin_bytes + lchunk * 16;
+        a_off2[i] = DUAL ? (long)mm * p.cin2_bytes + lchunk * 16 : 0;
         bh[i] = ok ? h0 : -(1 << 28);
         bw[i] = w0;
         wsrc[i] = p.w + (long)(n0 + row) * p.wrow_bytes + lchunk * 16;
@@ -108,6 +114,15 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
     int khi = 0, kwi = 0, kc = 0;   // tap / channel-stage of the NEXT pixel-row request
     const char *xsrc[2];
     auto prep_x = [&]() {           // source addresses of the next stage's two pixel-row pieces
+        if constexpr (DUAL) {       // kc counts the 32-channel stages of both inputs
+            const bool second = kc >= p.st_per_tap;
+            const char *base = second ? p.x2 : p.x;
+            const long toff = (long)(second ? kc - p.st_per_tap : kc) * R_ROWB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xsrc[i] = bh[i] >= 0 ? base + (second ? a_off2[i] : a_off[i]) + toff : p.zero;
+            kc += 1;
+            return;
+        }
         const int dh = khi * p.dil, dw = kwi * p.dil;
         const long toff = ((long)dh * p.W + dw) * p.cin_bytes + kc * R_ROWB;
 #pragma unroll
@@ -407,6 +422,17 @@ __global__ __launch_bounds__(512, 2) void conv_mfma256_kernel(Conv256K p) {
 #undef VK_LDS_BARRIER
 }
 
+bool conv256_dual_ok(const ConvArgs &a) {
+    const char *v = getenv("VK_CONV256_DUAL");           // "0": the two-per-CU kernel takes the dual-source form (A/B switch)
+    if (v && v[0] == '0') return false;
+    if (!a.x2 || a.stem || a.pool_part || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
+    if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
+    if (a.Cout % R_BN != 0 || a.ldy != a.Cout || a.Cin % 32 != 0 || a.Cin2 % 32 != 0 || (a.Cin + a.Cin2) % 64 != 0) return false;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    // measured on the Res5 shape (512 | 1024 -> 2048): worth it when the K loop is long; short K stays two-per-CU
+    return M >= 4 * R_BM && a.Cin + a.Cin2 >= 1024;
+}
+
 bool conv256_eligible(const ConvArgs &a) {
     static const bool disabled = getenv("VK_DISABLE_CONV256") != nullptr;
     if (disabled || a.stem) return false;
@@ -464,15 +490,17 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     VK_REQUIRE(M > 0 && M < (1L << 31) - R_BM, VK_EINVAL, "conv256: M=%ld out of range", M);
     k.M = (int)M;
     k.cin_bytes = a.Cin * 2;
+    k.x2 = (const char *)a.x2;
+    k.cin2_bytes = a.x2 ? a.Cin2 * 2 : 0;
     k.ldy = a.ldy;
     k.kw = a.kw;
     k.stride = a.stride;
     k.pad = a.pad;
     k.dil = a.dil;
     k.st_per_tap = a.Cin / 32;
-    k.stages = a.kh * a.kw * k.st_per_tap;
+    k.stages = a.x2 ? (a.Cin + a.Cin2) / 32 : a.kh * a.kw * k.st_per_tap;
     k.ntaps = a.kh * a.kw;
-    k.wrow_bytes = a.kh * a.kw * a.Cin * 2;
+    k.wrow_bytes = a.x2 ? (a.Cin + a.Cin2) * 2 : a.kh * a.kw * a.Cin * 2;
     k.relu = a.relu;
     k.m_tiles = ceil_div(k.M, R_BM);
     k.n_tiles = a.Cout / R_BN;
@@ -485,6 +513,15 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     }
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;   // re-read: lets one process A/B variants
     const dim3 grid(k.m_tiles * k.n_tiles), block(512);
+    if (a.x2) {
+        static bool dual_attr = false;
+        if (!dual_attr) {
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma256_kernel<0, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, R_SMEM));
+            dual_attr = true;
+        }
+        hipLaunchKernelGGL((conv_mfma256_kernel<0, true>), grid, block, R_SMEM, stream, k);
+    } else
     switch (dbg) {
         case 1: hipLaunchKernelGGL(conv_mfma256_kernel<1>, grid, block, R_SMEM, stream, k); break;
         case 2: hipLaunchKernelGGL(conv_mfma256_kernel<2>, grid, block, R_SMEM, stream, k); break;
@@ -500,9 +537,10 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({a.concurrent ? 6 : 0, 2.0 * (double)k.M * a.Cout * a.kh * a.kw * a.Cin, e0, e1, k.M, a.Cout, a.Cin, a.kh * a.kw, a.stride,
-                            2.0 * ((double)a.N * a.H * a.W * a.Cin + (double)k.M * a.Cout * (a.res ? 2 : 1) +
-                                   (double)a.Cout * a.kh * a.kw * a.Cin)});
+        const int K = a.kh * a.kw * a.Cin + (a.x2 ? a.Cin2 : 0);
+        tm->recs.push_back({a.concurrent ? 6 : 0, 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, a.x2 ? K : a.Cin, a.kh * a.kw, a.stride,
+                            2.0 * ((double)a.N * a.H * a.W * (a.Cin + (a.x2 ? a.Cin2 : 0)) + (double)k.M * a.Cout * (a.res ? 2 : 1) +
+                                   (double)a.Cout * K)});
     }
     return VK_OK;
 }

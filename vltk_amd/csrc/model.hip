@@ -147,6 +147,8 @@ struct vk_handle {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;                     // second stream of the res4 stage (half-batch pipelining)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t more_sides[2] = {nullptr, nullptr};  // third / fourth stream when backbone_streams is 3 / 4
+    hipEvent_t more_joins[2] = {nullptr, nullptr};
     bool ev_valid = false;
     // forwards in flight (vk_forward_begin .. vk_forward_end): ticket t uses slot t % VK_MAX_INFLIGHT
     static constexpr int VK_MAX_INFLIGHT = 4;
@@ -812,7 +814,7 @@ int vk_create(const vk_config *cfg, int device, vk_handle **out) {
     const char *env = getenv("VK_HEAD_CHUNK");
     if (env && atoi(env) > 0) h->head_chunk = atoi(env);
     if (const char *bs = getenv("VK_BACKBONE_STREAMS"))
-        if (bs[0] == '1' || bs[0] == '2') h->backbone_streams = bs[0] - '0';
+        if (bs[0] >= '1' && bs[0] <= '4') h->backbone_streams = bs[0] - '0';
     if (const char *hs = getenv("VK_HEAD_STREAMS"))
         if (hs[0] == '1' || hs[0] == '2') h->head_streams = hs[0] - '0';
     const int di = cfg->depth == 50 ? 0 : (cfg->depth == 101 ? 1 : 2);
@@ -988,7 +990,7 @@ int vk_set_option(vk_handle *h, const char *key, int value) {
         return VK_OK;
     }
     if (!strcmp(key, "backbone_streams")) {
-        VK_REQUIRE(value == 1 || value == 2, VK_EINVAL, "backbone_streams must be 1 or 2");
+        VK_REQUIRE(value >= 1 && value <= 4, VK_EINVAL, "backbone_streams must be 1..4");
         h->backbone_streams = value;
         return VK_OK;
     }
@@ -1025,6 +1027,10 @@ int vk_destroy(vk_handle *h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side) (void)hipStreamDestroy(h->side);
+    for (int i = 0; i < 2; ++i) {
+        if (h->more_joins[i]) (void)hipEventDestroy(h->more_joins[i]);
+        if (h->more_sides[i]) (void)hipStreamDestroy(h->more_sides[i]);
+    }
     delete h->ktimer;
     delete h;
     return VK_OK;
@@ -1139,22 +1145,37 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
     // two streams, so the tail of one half's layer k overlaps the other half's layer k (images are independent; the
     // halves touch disjoint parts of every buffer).  Option "backbone_streams" = 1 / VK_BACKBONE_STREAMS=1 disables it.
     for (int st = 0; st < 3; ++st) {
-        const bool split = h->backbone_streams == 2 && st >= 1 && N >= 2 && N >= h->backbone_split_min_batch && h->dt == VK_F16;
+        const bool split = h->backbone_streams >= 2 && st >= 1 && N >= h->backbone_streams && N >= h->backbone_split_min_batch && h->dt == VK_F16;
+        const int ns = split ? h->backbone_streams : 1;      // image groups, one stream each
+        hipStream_t gs_[4] = {s, nullptr, nullptr, nullptr};
+        hipEvent_t gj_[4] = {nullptr, nullptr, nullptr, nullptr};
         if (split) {
             if (!h->side) {
                 VK_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
                 VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
                 VK_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             }
+            for (int i = 0; i < ns - 2; ++i)
+                if (!h->more_sides[i]) {
+                    VK_CHECK_HIP(hipStreamCreateWithFlags(&h->more_sides[i], hipStreamNonBlocking));
+                    VK_CHECK_HIP(hipEventCreateWithFlags(&h->more_joins[i], hipEventDisableTiming));
+                }
+            gs_[1] = h->side;
+            gj_[1] = h->ev_join;
+            for (int i = 2; i < ns; ++i) {
+                gs_[i] = h->more_sides[i - 2];
+                gj_[i] = h->more_joins[i - 2];
+            }
             VK_CHECK_HIP(hipEventRecord(h->ev_fork, s));
-            VK_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            for (int i = 1; i < ns; ++i) VK_CHECK_HIP(hipStreamWaitEvent(gs_[i], h->ev_fork, 0));
         }
-        const int na = split ? N / 2 : N;
         for (auto &b : h->stages[st]) {
             int ho, wo;
             if (split) {
-                VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo, nullptr, 0, na));
-                VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, h->side, &ho, &wo, nullptr, na, N - na));
+                for (int i = 0; i < ns; ++i) {
+                    const int n0 = (int)((long)N * i / ns), n1 = (int)((long)N * (i + 1) / ns);
+                    VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, gs_[i], &ho, &wo, nullptr, n0, n1 - n0));
+                }
             } else {
                 VK_TRY(run_block(h, b, cur, N, ch, cw, p.bufT1, p.bufT2, p.bufSC, nxt, s, &ho, &wo));
             }
@@ -1163,8 +1184,10 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
             cw = wo;
         }
         if (split) {
-            VK_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
-            VK_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+            for (int i = 1; i < ns; ++i) {
+                VK_CHECK_HIP(hipEventRecord(gj_[i], gs_[i]));
+                VK_CHECK_HIP(hipStreamWaitEvent(s, gj_[i], 0));
+            }
         }
     }
     VK_REQUIRE(ch == p.Hf && cw == p.Wf, VK_EINVAL, "internal: res4 geometry mismatch (%dx%d vs %dx%d)", ch, cw, p.Hf, p.Wf);
