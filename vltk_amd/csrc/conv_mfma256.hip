@@ -538,7 +538,7 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
         const int K = a.kh * a.kw * a.Cin + (a.x2 ? a.Cin2 : 0);
-        tm->recs.push_back({a.concurrent ? 6 : 0, 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, a.x2 ? K : a.Cin, a.kh * a.kw, a.stride,
+        tm->recs.push_back({a.concurrent ? 6 : (a.x2 ? 9 : 0), 2.0 * (double)k.M * a.Cout * K, e0, e1, k.M, a.Cout, a.x2 ? K : a.Cin, a.kh * a.kw, a.stride,
                             2.0 * ((double)a.N * a.H * a.W * (a.Cin + (a.x2 ? a.Cin2 : 0)) + (double)k.M * a.Cout * (a.res ? 2 : 1) +
                                    (double)a.Cout * K)});
     }
