@@ -43,6 +43,7 @@ KERNEL_NAMES = {   # kernel_timing() bucket -> (rocprofv3 kernel name, descripti
     "other": ("conv_mfma_kernel", "stem / strict-mode convs"),
     "conv_ws": ("conv_ws_kernel", "1x1 conv with K <= 512, weight-stationary: 256 x K weights in registers, pixels through an LDS-DMA ring"),
     "conv_mfma256_dual": ("conv_mfma256_kernel<0, true>", "256x256 LDS-ring GEMM with two inputs (conv3 + projection shortcut, K = Cin | Cin2)"),
+    "conv_gemm4": ("conv_gemm4_kernel", "1x1 conv with K >= 1024 (one or two inputs): 256x256 tile, four waves of 128x128, LDS-DMA ring"),
     "conv3x3_blk": ("conv3x3_blk_kernel", "3x3 conv over 64-channel slabs (ResNeXt grouped conv2, dense 64->64), weights in registers"),
 }
 
@@ -387,7 +388,7 @@ def main():
                          "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
                          "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 5),
                          "alg_gflop_per_image": round(conv_gflop_per_image(a.proposals, a.arch), 1),
-                         "per_kernel": {KERNEL_NAMES[k][0] + ("" if k in ("conv_mfma256", "conv3x3_panel", "conv_duo", "conv3x3_blk", "conv_ws", "conv_mfma256_dual") else ":" + k):
+                         "per_kernel": {KERNEL_NAMES[k][0] + ("" if k in ("conv_mfma256", "conv3x3_panel", "conv_duo", "conv3x3_blk", "conv_ws", "conv_mfma256_dual", "conv_gemm4") else ":" + k):
                                         {"launches": v["launches"], "ms_per_step": round(v["ms"] / a.steps, 3),
                                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                         for k, v in kt.items() if v["ms"] > 0},

@@ -178,9 +178,10 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
  * bucket 8: conv_ws_kernel (1x1, K <= 512, weight-stationary: a workgroup keeps its 256 x K weights in registers)
  * bucket 9: conv_mfma256_kernel<0, true> (the ring kernel's two-input build: conv3 + projection shortcut as one GEMM; its own
  *           symbol in a rocprofv3 trace)
- * launches[10], ms[10], flops[10] (algorithmic 2*M*Cout*K of the launches), bytes[10] (algorithmic HBM bytes:
+ * bucket 10: conv_gemm4_kernel (1x1 with K >= 1024, one or two inputs: 256x256 tile, four waves of 128x128)
+ * launches[11], ms[11], flops[11] (algorithmic 2*M*Cout*K of the launches), bytes[11] (algorithmic HBM bytes:
  * input + output (+ residual) + weights, each once). */
-#define VK_NUM_KERNEL_BUCKETS 10
+#define VK_NUM_KERNEL_BUCKETS 11
 int vk_enable_kernel_timing(vk_handle *h, int enable);
 int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 

@@ -33,5 +33,27 @@ def test_scanner_flags_a_copy_of_a_pending_read():
 def test_no_inflight_register_use(src):
     res = chk.scan_file(os.path.join(chk.CSRC, src))
     assert res, "no kernels found"
+    if src == "conv_gemm4.hip":      # its timing-only ablation builds (DBG != 0) replace fragment reads by dummies: not product code
+        res = {k: v for k, v in res.items() if "ELi0EEE" in k}
+        assert res
     bad = {k: v[:3] for k, v in res.items() if v}
     assert not bad, bad
+
+
+def test_asm_mfma_scanner():
+    code = [";;#ASMSTART", "v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]", ";;#ASMEND",
+            "v_accvgpr_read_b32 v9, a0",               # one instruction after the MFMA that writes a0: stale
+            "s_add_i32 s1, s1, 1", "v_mov_b32_e32 v20, v21", "v_cndmask_b32_e32 v4, v8, v9, vcc",
+            ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 a[4:7], v[0:3], v[4:7], a[4:7]", ";;#ASMEND", "v_accvgpr_read_b32 v10, a4"]
+    assert [t.split()[0] for _, t in chk.scan_asm_mfma_region(code)] == ["v_accvgpr_read_b32", "v_cndmask_b32_e32"]
+    assert chk.scan_asm_mfma_region(["v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]", "v_accvgpr_read_b32 v9, a0"]) == []
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_gemm4_loop_has_no_compiler_valu():
+    """conv_gemm4.hip writes its MFMAs as asm: between the first and the last of them the product build must hold no
+    accumulator traffic and no compiler-generated VALU instruction (both were real bugs: see the kernel's comments)."""
+    res = chk.scan_file(os.path.join(chk.CSRC, "conv_gemm4.hip"), scan=chk.scan_asm_mfma_region)
+    prod = {k: v for k, v in res.items() if "Lb0ELi0E" in k}
+    assert prod, list(res)
+    assert all(not v for v in prod.values()), {k: v[:4] for k, v in prod.items() if v}

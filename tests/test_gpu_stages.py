@@ -174,13 +174,17 @@ def test_conv1x1_dual(M, c1, c2, cout, res, monkeypatch):
     wcat = torch.cat([p1.view(rows, c1 * 2), p2.view(rows, c2 * 2)], dim=1).contiguous()
     x1d, x2d, rd = x1.to(G.DEV), x2.to(G.DEV), (r.to(G.DEV) if res else None)
     y = torch.empty((M, cout), dtype=torch.float16, device=G.DEV)
+    monkeypatch.setenv("VK_CONV_GEMM4", "2")                # the four-wave GEMM also on grids this small
     L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y), cout, 1, G.stream())
     torch.cuda.synchronize()
-    monkeypatch.setenv("VK_CONV256_DUAL", "0")              # the two-per-CU kernel on the same layer
-    y_duo = torch.full_like(y, float("nan"))
-    L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y_duo), cout, 1, G.stream())
-    torch.cuda.synchronize()
-    assert torch.equal(y, y_duo)
+    # the same layer on the other kernels that take it: four-wave GEMM (K >= 1024) -> ring kernel -> two-per-CU kernel
+    for off in (("VK_CONV_GEMM4",), ("VK_CONV_GEMM4", "VK_CONV256_DUAL")):
+        for k in off:
+            monkeypatch.setenv(k, "0")
+        y2 = torch.full_like(y, float("nan"))
+        L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y2), cout, 1, G.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), off
     f1, fb1 = G.fold_ref(w1, bn1, L.VK_F16)
     f2, fb2 = G.fold_ref(w2, bn2, L.VK_F16)
     ref = x1.float() @ f1.view(cout, c1).t() + x2.float() @ f2.view(cout, c2).t() + (fb1 + fb2)
@@ -306,6 +310,34 @@ def test_conv_ws_kernel_bit_identical(M_hw, cin, cout, res, monkeypatch):
     if res:
         ref = ref + r.half().float()
     assert G.rel_err(ys[0], F.relu(ref).half().float()) <= 1e-3
+
+
+@pytest.mark.parametrize("M_hw,cin,cout,res,relu", [((13, 14, 14), 2048, 512, False, True), ((11, 14, 14), 1024, 512, False, True),
+                                                    ((17, 14, 14), 1024, 256, True, True), ((2, 50, 84), 1024, 256, False, False),
+                                                    ((1, 45, 47), 1152, 512, True, False)])
+def test_conv_gemm4_kernel_bit_identical(M_hw, cin, cout, res, relu, monkeypatch):
+    """conv_gemm4.hip (1x1, K >= 1024: 256 x 256 tile, four waves of 128 x 128, accumulators in AGPRs) against the kernels that
+    take the layer without it (two-per-CU / ring): bit-identical, with full and ragged tiles, with and without residual / ReLU,
+    and nine groups of four stages (K = 1152)."""
+    N, H, W = M_hw
+    g = _rng(cin + cout + N)
+    x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = (g.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    r = torch.from_numpy(g.standard_normal((N, cout, H, W)).astype(np.float32)) if res else None
+    ys = []
+    for g4, duo in (("2", "1"), ("0", "1"), ("0", "0"), ("2", "1")):      # "2": also on grids this small
+        monkeypatch.setenv("VK_CONV_GEMM4", g4)
+        monkeypatch.setenv("VK_CONV_DUO", duo)
+        ys.append(G.conv2d(x, w, bn=bn, residual_nchw=r, relu=relu, dt=L.VK_F16))
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    wf, bf = G.fold_ref(w, bn, L.VK_F16)
+    ref = F.conv2d(x.half().float(), wf) + bf.view(1, -1, 1, 1)
+    if res:
+        ref = ref + r.half().float()
+    if relu:
+        ref = F.relu(ref)
+    assert G.rel_err(ys[0], ref.half().float()) <= 1e-3
 
 
 def test_conv_bias_f32_out():

@@ -375,6 +375,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         return launch_conv_duo(a, stream);
     }
     if (a.x2) {
+        if (conv_gemm4_eligible(a)) return launch_conv_gemm4(a, stream);
         if (conv256_dual_ok(a)) return launch_conv256(a, stream);
         VK_REQUIRE(conv_duo_dual_ok(a), VK_EINVAL,
                    "conv: the dual-source form is 1x1, stride 1, f16, Cout %% 256 == 0, Cin and Cin2 multiples of 32");
@@ -384,6 +385,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (!grouped) {
         if (conv3x3_panel_eligible(a)) return launch_conv3x3_panel(a, stream);
         if (conv_ws_eligible(a)) return launch_conv_ws(a, stream);
+        if (conv_gemm4_eligible(a)) return launch_conv_gemm4(a, stream);
         if (conv_duo_eligible(a)) return launch_conv_duo(a, stream);
         if (conv256_eligible(a)) return launch_conv256(a, stream);
     }
