@@ -45,8 +45,10 @@ def test_asm_mfma_scanner():
             "v_accvgpr_read_b32 v9, a0",               # one instruction after the MFMA that writes a0: stale
             "s_add_i32 s1, s1, 1", "v_mov_b32_e32 v20, v21", "v_cndmask_b32_e32 v4, v8, v9, vcc",
             ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 a[4:7], v[0:3], v[4:7], a[4:7]", ";;#ASMEND", "v_accvgpr_read_b32 v10, a4"]
-    assert [t.split()[0] for _, t in chk.scan_asm_mfma_region(code)] == ["v_accvgpr_read_b32", "v_cndmask_b32_e32"]
+    assert [t.split()[0] for _, t in chk.scan_asm_mfma_region(code)] == ["v_accvgpr_read_b32", "v_cndmask_b32_e32", "v_accvgpr_read_b32"]
     assert chk.scan_asm_mfma_region(["v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]", "v_accvgpr_read_b32 v9, a0"]) == []
+    fenced = [";;#ASMSTART", "v_mfma_f32_16x16x32_f16 a[0:3], v[0:3], v[4:7], a[0:3]", ";;#ASMEND", "s_nop 15", "s_nop 15", "v_accvgpr_read_b32 v9, a0"]
+    assert chk.scan_asm_mfma_region(fenced) == []
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")

@@ -120,35 +120,39 @@ def scan_function(lines):
     return found
 
 
-def scan_asm_mfma_region(lines):
+def scan_asm_mfma_region(lines, min_states=20):
     """Kernels whose MFMAs are written as asm (conv_gemm4.hip): hipcc does not know those statements are matrix instructions, so
     it inserts none of the wait states an MFMA needs around it and treats an operand register as free the instruction after.
-    Between the first and the last asm MFMA there must therefore be (a) no accumulator traffic (v_accvgpr_*: a read one
-    instruction after the MFMA that produces the value returned stale results on MI355X), and (b) no compiler-generated VALU
-    instruction except plain v_mov_b32 between long-lived registers (an address temporary allocated in a just-consumed operand
-    register corrupted that operand).  Returns [(line index, text)]; [] if the function has no asm MFMA."""
-    in_asm = False
-    mf = []
-    for i, ln in enumerate(lines):
-        t = ln.strip()
-        if t.startswith(";;#ASMSTART"):
-            in_asm = True
-        elif t.startswith(";;#ASMEND"):
-            in_asm = False
-        elif in_asm and t.startswith("v_mfma"):
-            mf.append(i)
-    if not mf:
-        return []
+    Flagged: every compiler-generated VALU / accumulator instruction (anything `v_*` outside an asm block, plain v_mov_b32
+    between long-lived registers excepted) issued fewer than `min_states` wait states after an asm MFMA (an instruction counts
+    1, `s_nop k` counts k + 1).  Both forms were real bugs on MI355X: a v_accvgpr_read one instruction after the MFMA that
+    produces the value returned stale results, and an address temporary allocated in a just-consumed operand register
+    corrupted that operand.  Returns [(line index, text)]; [] if the function has no asm MFMA."""
     bad = []
     in_asm = False
-    for i in range(0, mf[-1]):
-        t = lines[i].strip()
+    since = None                      # wait states since the last asm MFMA
+    for i, ln in enumerate(lines):
+        t = ln.strip()
+        if not t or t.startswith(";") and not t.startswith(";;#ASM"):
+            continue
         if t.startswith(";;#ASMSTART"):
             in_asm = True
-        elif t.startswith(";;#ASMEND"):
+            continue
+        if t.startswith(";;#ASMEND"):
             in_asm = False
-        elif i > mf[0] and not in_asm and t.startswith("v_") and not t.startswith("v_mov_b32"):
-            bad.append((i - mf[0], t))
+            continue
+        if t.endswith(":") or t.startswith("."):
+            continue
+        if in_asm and t.startswith("v_mfma"):
+            since = 0
+            continue
+        if since is None:
+            continue
+        # (v_readlane / v_writelane: hipcc's SGPR spill traffic through a register it reserves for that)
+        if not in_asm and t.startswith("v_") and not t.startswith(("v_mov_b32", "v_readlane_b32", "v_writelane_b32")) and since < min_states:
+            bad.append((i, t))
+        m = re.match(r"s_nop\s+(\d+)", t)
+        since += int(m.group(1)) + 1 if m else 1
     return bad
 
 

@@ -45,12 +45,19 @@ def main():
     torch.cuda.synchronize()
     del os.environ["VK_GEMM4_STAMPS"]
     rows = np.array([[int(v) for v in ln.split()] for ln in open(out) if not ln.startswith("#")], dtype=np.float64)
-    cyc, rt, S = rows[:, 1], rows[:, 2], rows[0, 3]
+    cyc, rt = rows[:, 1], rows[:, 2]
+    S = cin // 32
     clk = np.median(cyc / rt) * 100e6
     print(f"{name}: {len(rows)} workgroups, {S:.0f} stages each; in-kernel clock {clk / 1e9:.3f} GHz (p10 {np.percentile(cyc / rt, 10) / 10:.3f}, "
           f"p90 {np.percentile(cyc / rt, 90) / 10:.3f})")
     print(f"  K loop: median {np.median(cyc):.0f} cycles = {np.median(cyc) / S:.0f} per stage (1024 = matrix pipe always busy: "
           f"{1024 * S / np.median(cyc) * 100:.1f} %), p10 {np.percentile(cyc, 10) / S:.0f}, p90 {np.percentile(cyc, 90) / S:.0f}")
+    if rows.shape[1] >= 9:
+        tiles = rows[:, 8]
+        print(f"  kernel span (first workgroup start to last workgroup end) {(rows[:, 4].max() - rows[:, 3].min()) / 100:.1f} us; workgroup start spread "
+              f"{(rows[:, 3].max() - rows[:, 3].min()) / 100:.1f} us, end spread {(rows[:, 4].max() - rows[:, 4].min()) / 100:.1f} us")
+        print(f"  per tile (us): zero + wait for stage 0 {np.median(rows[:, 5] / tiles) / 100:.2f}, K loop {np.median(rows[:, 6] / tiles) / 100:.2f}, "
+              f"epilogue incl. its store acknowledgements {np.median(rows[:, 7] / tiles) / 100:.2f}  ({np.median(tiles):.0f} tiles per workgroup)")
     print(f"  MFMA peak at this clock: {clk * 1024 * 1024 / 1e12:.0f} TFLOP/s")
 
 

@@ -21,12 +21,11 @@ find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OU
 # two-stream backbone section carry other template arguments)
 python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_duo.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv3x3_panel_kernel<3, 0, 0>" --json $OUT/${TAG}_pmc_panel.json --name conv3x3_panel_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
-python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_mfma256_kernel<0, false>" --json $OUT/${TAG}_pmc_ring.json --name conv_mfma256_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
-python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_mfma256_kernel<0, true>" --json $OUT/${TAG}_pmc_ringdual.json --name "conv_mfma256_kernel<0, true>" --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_gemm4_kernel" --json $OUT/${TAG}_pmc_gemm4.json --name conv_gemm4_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_ws_kernel" --json $OUT/${TAG}_pmc_ws.json --name conv_ws_kernel --batch 32 --proposals 300 --min-workgroups 200 >> $OUT/${TAG}_pmc_summary.txt
 python - <<PY
 import json
-ks = [json.load(open("$OUT/${TAG}_pmc_%s.json" % k)) for k in ("panel", "duo", "ring", "ringdual", "ws")]
+ks = [json.load(open("$OUT/${TAG}_pmc_%s.json" % k)) for k in ("panel", "gemm4", "duo", "ws")]
 json.dump({"batch": 32, "proposals": 300, "kernels": ks}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
 PY
 # keep only the summaries (the raw traces are large)

@@ -49,33 +49,41 @@ struct Gemm4K {
 constexpr int G_ROWB = 64, G_NSLOT = 4;
 constexpr int G_XB = 256 * G_ROWB;           // 16 KiB
 constexpr int G_SLOT = 2 * G_XB;             // 32 KiB
-constexpr int G_SMEM = G_NSLOT * G_SLOT;     // 128 KiB
+constexpr int G_SMEM = G_NSLOT * G_SLOT;     // 128 KiB (the ring; the layer's bias, Cout x 4 B, sits behind it)
 
 #define VKG_GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-// STAMP: diagnostic build (VK_GEMM4_STAMPS=<file>): wave 0 stamps s_memtime / s_memrealtime around the K loop into a buffer
-// nothing else reads (in-kernel clock and cycles per stage: tools/gemm4_stamps.py); never used by the product path
+// STAMP: diagnostic build (VK_GEMM4_STAMPS=<file>): wave 0 stamps s_memtime / s_memrealtime around the first tile's K loop and
+// sums the phases of all its tiles into a buffer nothing else reads (tools/gemm4_stamps.py); never used by the product path
 // DBG (STAMP builds, timing only, WRONG results; VK_GEMM4_DBG): 1 = no LDS-DMA in the steady state, 2 = no stage barrier there,
 // 4 = no pixel-row fragment reads there, 8 = no weight fragment reads there
+struct Gemm4Tile {                      // what depends on the tile: origin, the lane's row indices, the three descriptors
+    int m0, n0;
+    unsigned xi[4];
+    __amdgpu_buffer_rsrc_t rx1, rx2, rw;
+};
+
 template <bool STAMP, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // XCD-aware (bijective) workgroup -> tile map, column tiles of one row tile next to each other on one XCD (conv_mfma.hip)
-    const int bid = blockIdx.x, nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int n_tile = t % p.n_tiles, m_tile = t / p.n_tiles;
-    const int m0 = m_tile * 256, n0 = n_tile * 256;
+    // PERSISTENT workgroups, one per CU (the launcher sizes the grid), each walking tiles bid, bid + grid, ... as ONE stream of
+    // K stages: the ring does not stop at a tile boundary -- the last four stages of a tile request the first stages of the next
+    // one (S % 4 == 0, so the slots line up), and a tile's epilogue sits between two MFMA rows with nothing to wait for.
+    // (A workgroup per tile paid, per tile, the first stage's HBM latency, the store tail and a dispatch: 14 % of its time.)
+    // XCD-aware (bijective) tile map, column tiles of one row tile next to each other on one XCD (conv_mfma.hip); the grid is
+    // a multiple of 8 (or the whole tile count), so a workgroup's tiles all map to its own XCD.
+    const int bid = blockIdx.x;
+    const int total_tiles = p.m_tiles * p.n_tiles;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int g = lane >> 4, j = lane & 15;
 
-    // RULE OF THIS LOOP: no compiler-generated VALU instruction inside it.  The MFMAs are asm (below), so hipcc does not know
+    // RULE OF THE K LOOP: no compiler-generated VALU instruction inside it.  The MFMAs are asm (below), so hipcc does not know
     // that a VGPR it sees as dead right after the last MFMA of a row is still being read by the matrix pipe: an address
     // temporary allocated there (v_cndmask / v_add for a DMA piece) corrupted the operand -- wrong rows, found by the bit-identity
     // tests.  Every per-lane address is therefore a loop-invariant register, what advances per stage is scalar, and the LDS
@@ -91,32 +99,40 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     // swizzled 16-byte chunk (constant per lane); the K advance is the scalar offset.  Weight rows: raw buffer, 32-bit offset.
     const int lrow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);   // logical 16-B chunk whose bytes land at phys chunk lane&3
-    unsigned xi[4], wv[4];
+    unsigned wv[4];
     const unsigned xo = lchunk * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 16 + lrow;
-        xi[i] = (unsigned)(min(m0 + row, p.M - 1) - m0);     // rows past M are computed and dropped
-        wv[i] = (unsigned)row * (unsigned)p.wrow_bytes + lchunk * 16;
-    }
-    const __amdgpu_buffer_rsrc_t rx1 =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)m0 * p.cin_bytes), (short)p.cin_bytes, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((p.x2 ? p.x2 : p.x) + (long)m0 * p.cin2_bytes), (short)(p.x2 ? p.cin2_bytes : p.cin_bytes), 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)(p.w + (long)n0 * p.wrow_bytes), 0, 0x7fffffff, 0x00020000);
+    for (int i = 0; i < 4; ++i) wv[i] = (unsigned)((wave * 4 + i) * 16 + lrow) * (unsigned)p.wrow_bytes + lchunk * 16;
+    auto setup_tile = [&](int tt, Gemm4Tile &T) {
+        const int nwg = total_tiles;
+        const int q = nwg >> 3, r = nwg & 7, xcd = tt & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tt >> 3);
+        const int n_tile = t % p.n_tiles, m_tile = t / p.n_tiles;
+        T.m0 = m_tile * 256;
+        T.n0 = n_tile * 256;
+        int stid = threadIdx.x;                             // opaque copy: nothing per-lane has to stay alive across the K loop for this
+        asm volatile("" : "+v"(stid));
+        const int slrow = (stid & 63) >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T.xi[i] = (unsigned)min((wave * 4 + i) * 16 + slrow, p.M - 1 - T.m0);   // rows past M are computed and dropped
+        T.rx1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)T.m0 * p.cin_bytes), (short)p.cin_bytes, 0x7fffffff, 0x00020000);
+        T.rx2 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.x2 ? p.x2 : p.x) + (long)T.m0 * p.cin2_bytes),
+                                                  (short)(p.x2 ? p.cin2_bytes : p.cin_bytes), 0x7fffffff, 0x00020000);
+        T.rw = __builtin_amdgcn_make_buffer_rsrc((void *)(p.w + (long)T.n0 * p.wrow_bytes), 0, 0x7fffffff, 0x00020000);
+    };
     const int dma_x0 = (wave * 4) * 1024;                  // byte offset of this wave's first pixel-row piece in a slot
     const int dma_w0 = G_XB + (wave * 4) * 1024;
     bool steady = false;                                    // DBG builds: inside the FULL loop
-    // stage = the (runtime) K stage the piece belongs to, slot = stage & 3 (compile time in the loop body)
-    auto req_x = [&](int stage, int slot, int i) {
+    // stage = the K stage (of tile T) the piece belongs to, slot = its ring slot (compile time in the loop body)
+    auto req_x = [&](const Gemm4Tile &T, int stage, int slot, int i) {
         if ((DBG & 1) && steady) return;
         const bool second = stage >= st1;                   // uniform
-        __builtin_amdgcn_struct_ptr_buffer_load_lds(second ? rx2 : rx1, (__attribute__((address_space(3))) void *)(smem + slot * G_SLOT + dma_x0 + i * 1024),
-                                                    16, xi[i], xo, (second ? stage - st1 : stage) * G_ROWB, 0, 0);
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(second ? T.rx2 : T.rx1, (__attribute__((address_space(3))) void *)(smem + slot * G_SLOT + dma_x0 + i * 1024),
+                                                    16, T.xi[i], xo, (second ? stage - st1 : stage) * G_ROWB, 0, 0);
     };
-    auto req_w = [&](int stage, int slot, int i) {
+    auto req_w = [&](const Gemm4Tile &T, int stage, int slot, int i) {
         if ((DBG & 1) && steady) return;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void *)(smem + slot * G_SLOT + dma_w0 + i * 1024), 16, wv[i],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(T.rw, (__attribute__((address_space(3))) void *)(smem + slot * G_SLOT + dma_w0 + i * 1024), 16, wv[i],
                                                  stage * G_ROWB, 0, 0);
     };
 
@@ -134,20 +150,12 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     }
     asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(wa0[0]), "+v"(wa0[1]), "+v"(wa1[0]), "+v"(wa1[1]));   // six registers, not re-derived in the loop
 
-    floatx4 acc[8][8];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // pin the zeroing HERE: hipcc otherwise sinks it to just before each accumulator's first (asm) MFMA, and since it does not see
-    // that statement as a matrix instruction it leaves out the wait states a v_accvgpr write needs before an MFMA reads the
-    // register as SrcC -- elements 2 and 3 of every accumulator came out wrong (found by the bit-identity tests)
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
-    asm volatile("s_nop 7" ::: "memory");
+    // the layer's bias goes to LDS once (behind the ring): an epilogue that loaded it from memory would wait, in order, behind
+    // the next tile's requests
+    float *bias_lds = reinterpret_cast<float *>(smem + G_SMEM);
+    for (int c = tid; c < p.ldy; c += 256) bias_lds[c] = p.bias[c];
 
+    floatx4 acc[8][8];
     // Fragment registers: two weight sets (current / next stage) and a 4-deep rotating window of pixel-row fragments.  The
     // reads and their COUNTED waits are issued by hand; LDS returns in order.
     half8 wa[8], wb[8], xw[4];
@@ -201,6 +209,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     } while (0)
 #define VKG_WAIT2(reg) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(reg))
 #define VKG_NONE ((void)0)
+#define VKG_IC(V) std::integral_constant<int, (V)> {}
+
+    Gemm4Tile A, B;                          // this tile and the workgroup's next one
+    int has_next = 0;                        // workgroup-uniform scalar: this tile is not the workgroup's last
 
     // The K loop is cut into PRE(s) = rows 0-4 of stage s, ending at the in-stage barrier, and POST(s) = rows 5-7 of stage s
     // together with the first fragment reads of stage s+1; a loop iteration is POST + PRE four times (slots 0..3), so every loop
@@ -211,83 +223,74 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     //     weight fragments, rows 6 / 7 the next stage's rows 0-2 (each after the row that consumed its register).
     //   DMA pieces: PRE(s) issues the LAST pixel piece of stage s+3 in row 0 and the four weight pieces of stage s+3 in rows 1-4;
     //     POST(s) the first three pixel pieces of stage s+4 (into the slot PRE(s)'s barrier freed).  Newer than the last piece of
-    //     stage s+1 at PRE(s)'s wait: the 8 pieces of stage s+2 and of stage s+3.
-    // SL = s & 3 and REM = S - s (stages left including this one; 99 = steady state) are compile-time constants: which requests
-    // and waits exist is decided per copy of the code, so there is no run-time flag (hipcc turns those into VALU compares).
+    //     stage s+1 at PRE(s)'s wait: the 8 pieces of stage s+2 and of stage s+3 -- and, just after a tile boundary, the previous
+    //     tile's stores: they only make the wait longer (loads and stores do not retire in order with each other, so no count
+    //     that had to EXCLUDE them would be safe).
+    // SL = s & 3, REM = S - s (stages left including this one; 99 = steady state) and CONT (the workgroup has a next tile:
+    // stages beyond this tile's are the next tile's first ones) are compile-time constants: which requests and waits exist is
+    // decided per copy of the code, so there is no run-time flag (hipcc turns those into VALU compares).
     auto pre = [&](auto rem_c, auto sl_c, int s, const half8 (&wcur)[8]) {
         constexpr int REM = decltype(rem_c)::value;
         constexpr bool FULL = REM == 99;
         constexpr int SL = decltype(sl_c)::value, S3 = (SL + 3) & 3;
-        constexpr bool more = REM > 1;
-        constexpr bool rq = REM > 3;              // stage s+3 exists: its last pixel piece and its weight pieces
+        // stage s+3: of this tile, or of the next one (its stage 3 - REM)
+#define VKG_RQX3() do { if constexpr (REM > 3) req_x(A, s + 3, S3, 3); else req_x(B, 3 - REM, S3, 3); } while (0)
+#define VKG_RQW(I) do { if constexpr (REM > 3) req_w(A, s + 3, S3, I); else req_w(B, 3 - REM, S3, I); } while (0)
         VKG_WAIT2(xw[0]); VKG_SB();
-        VKG_ROW(0, xw[0], wcur, VKG_DSRX(xw[3], SL, 3072, FULL), if constexpr (rq) req_x(s + 3, S3, 3), VKG_NONE, VKG_NONE);
+        VKG_ROW(0, xw[0], wcur, VKG_DSRX(xw[3], SL, 3072, FULL), VKG_RQX3(), VKG_NONE, VKG_NONE);
         VKG_WAIT2(xw[1]); VKG_SB();
-        VKG_ROW(1, xw[1], wcur, VKG_DSRX(xw[0], SL, 4096, FULL), if constexpr (rq) req_w(s + 3, S3, 0), VKG_NONE, VKG_NONE);
+        VKG_ROW(1, xw[1], wcur, VKG_DSRX(xw[0], SL, 4096, FULL), VKG_RQW(0), VKG_NONE, VKG_NONE);
         VKG_WAIT2(xw[2]); VKG_SB();
-        VKG_ROW(2, xw[2], wcur, VKG_DSRX(xw[1], SL, 5120, FULL), if constexpr (rq) req_w(s + 3, S3, 1), VKG_NONE, VKG_NONE);
+        VKG_ROW(2, xw[2], wcur, VKG_DSRX(xw[1], SL, 5120, FULL), VKG_RQW(1), VKG_NONE, VKG_NONE);
         VKG_WAIT2(xw[3]); VKG_SB();
-        VKG_ROW(3, xw[3], wcur, VKG_DSRX(xw[2], SL, 6144, FULL), if constexpr (rq) req_w(s + 3, S3, 2), VKG_NONE, VKG_NONE);
+        VKG_ROW(3, xw[3], wcur, VKG_DSRX(xw[2], SL, 6144, FULL), VKG_RQW(2), VKG_NONE, VKG_NONE);
         VKG_WAIT2(xw[0]); VKG_SB();
-        VKG_ROW(4, xw[0], wcur, VKG_DSRX(xw[3], SL, 7168, FULL), if constexpr (rq) req_w(s + 3, S3, 3), VKG_NONE, VKG_NONE);
+        VKG_ROW(4, xw[0], wcur, VKG_DSRX(xw[3], SL, 7168, FULL), VKG_RQW(3), VKG_NONE, VKG_NONE);
+#undef VKG_RQX3
+#undef VKG_RQW
         // every read of stage s is issued; wait for them in straight-line code
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
         VKG_SB();
-        if constexpr (more) {
-            if constexpr (FULL && (DBG & 2))
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr (REM > 3)
-                asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            else if constexpr (REM > 2)
-                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        if constexpr (FULL && (DBG & 2))
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else                                   // (also in a tile's last stages: the stream goes on, two stages in flight behind stage s+1)
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         VKG_SB();
     };
     auto post = [&](auto rem_c, auto sl_c, int s, const half8 (&wcur)[8], half8 (&wnext)[8]) {
         constexpr int REM = decltype(rem_c)::value;
         constexpr bool FULL = REM == 99;
         constexpr int SL = decltype(sl_c)::value, SN = (SL + 1) & 3;          // this stage's slot (== the slot of stage s+4), the next stage's
-        constexpr bool rx = REM > 4;
-#define VKG_W2(A, B, OFF)                                                     \
-    do {                                                                      \
-        if constexpr ((DBG & 8) && FULL) {                                    \
-            asm volatile("" : "+v"(wnext[A]), "+v"(wnext[B]) : "v"(wa0[0]));  \
-        } else {                                                              \
-            VKG_DSR(wnext[A], wa0, SN, OFF);                                  \
-            VKG_DSR(wnext[B], wa1, SN, OFF);                                  \
-        }                                                                     \
+#define VKG_RQX(I) do { if constexpr (REM > 4) req_x(A, s + 4, SL, I); else req_x(B, 4 - REM, SL, I); } while (0)
+#define VKG_W2(A_, B_, OFF)                                                     \
+    do {                                                                        \
+        if constexpr ((DBG & 8) && FULL) {                                      \
+            asm volatile("" : "+v"(wnext[A_]), "+v"(wnext[B_]) : "v"(wa0[0]));  \
+        } else {                                                                \
+            VKG_DSR(wnext[A_], wa0, SN, OFF);                                   \
+            VKG_DSR(wnext[B_], wa1, SN, OFF);                                   \
+        }                                                                       \
     } while (0)
         VKG_ROW(5, xw[1], wcur, VKG_W2(0, 1, 0), VKG_W2(2, 3, 2048), VKG_W2(4, 5, 4096), VKG_W2(6, 7, 6144));
-        VKG_ROW(6, xw[2], wcur, VKG_DSRX(xw[0], SN, 0, FULL), if constexpr (rx) req_x(s + 4, SL, 0), VKG_DSRX(xw[1], SN, 1024, FULL), if constexpr (rx) req_x(s + 4, SL, 1));
-        VKG_ROW(7, xw[3], wcur, VKG_DSRX(xw[2], SN, 2048, FULL), if constexpr (rx) req_x(s + 4, SL, 2), VKG_NONE, VKG_NONE);
+        VKG_ROW(6, xw[2], wcur, VKG_DSRX(xw[0], SN, 0, FULL), VKG_RQX(0), VKG_DSRX(xw[1], SN, 1024, FULL), VKG_RQX(1));
+        VKG_ROW(7, xw[3], wcur, VKG_DSRX(xw[2], SN, 2048, FULL), VKG_RQX(2), VKG_NONE, VKG_NONE);
 #undef VKG_W2
+#undef VKG_RQX
     };
-    auto last_rows = [&](const half8 (&wcur)[8]) {
-        VKG_ROW(5, xw[1], wcur, VKG_NONE, VKG_NONE, VKG_NONE, VKG_NONE);
-        VKG_ROW(6, xw[2], wcur, VKG_NONE, VKG_NONE, VKG_NONE, VKG_NONE);
-        VKG_ROW(7, xw[3], wcur, VKG_NONE, VKG_NONE, VKG_NONE, VKG_NONE);
-    };
-#define VKG_IC(V) std::integral_constant<int, (V)> {}
-
-    // prologue (S >= 8 and S % 4 == 0, the launcher checks): stages 0..2 completely, and the first three pixel pieces of stage 3
-    // (its last pixel piece and its weight pieces ride on stage 0)
+    // ---- the workgroup's first tile: stages 0..2 completely and the first three pixel pieces of stage 3 (S >= 8 and S % 4 == 0,
+    // the launcher checks); every later tile finds exactly this state, left by its predecessor's last four stages ----
+    setup_tile(bid, A);
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) req_x(st, st, i);
+        for (int i = 0; i < 4; ++i) req_x(A, st, st, i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) req_w(st, st, i);
+        for (int i = 0; i < 4; ++i) req_w(A, st, st, i);
     }
-    req_x(3, 3, 0);
-    req_x(3, 3, 1);
-    req_x(3, 3, 2);
-    asm volatile("s_waitcnt vmcnt(19)\n\ts_barrier" ::: "memory");     // stage 0 (the 8 oldest of 27 pieces) has landed
-    unsigned long t_c0 = 0, t_r0 = 0;
-    if constexpr (STAMP) {
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c0), "=s"(t_r0)::"memory");
-    }
+    req_x(A, 3, 3, 0);
+    req_x(A, 3, 3, 1);
+    req_x(A, 3, 3, 2);
+    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // stage 0 (the 8 oldest of 27 pieces) has landed; bias is in LDS
     VKG_DSR(wa[0], wa0, 0, 0);
     VKG_DSR(wa[1], wa1, 0, 0);
     VKG_DSR(wa[2], wa0, 0, 2048);
@@ -299,112 +302,155 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     VKG_DSR(xw[0], xa, 0, 0);
     VKG_DSR(xw[1], xa, 0, 1024);
     VKG_DSR(xw[2], xa, 0, 2048);
-    pre(VKG_IC(99), VKG_IC(0), 0, wa);
-    int s = 0;
-    steady = true;
-    for (; s + 8 < S; s += 4) {            // four stages per iteration: the slots are compile-time constants
-        post(VKG_IC(99), VKG_IC(0), s, wa, wb);
-        pre(VKG_IC(99), VKG_IC(1), s + 1, wb);
-        post(VKG_IC(99), VKG_IC(1), s + 1, wb, wa);
-        pre(VKG_IC(99), VKG_IC(2), s + 2, wa);
-        post(VKG_IC(99), VKG_IC(2), s + 2, wa, wb);
-        pre(VKG_IC(99), VKG_IC(3), s + 3, wb);
-        post(VKG_IC(99), VKG_IC(3), s + 3, wb, wa);
-        pre(VKG_IC(99), VKG_IC(0), s + 4, wa);
-    }
-    steady = false;
-    // s == S - 8 here (S % 4 == 0): the last eight stages, every copy knowing how many stages are left
-    post(VKG_IC(8), VKG_IC(0), s, wa, wb);
-    pre(VKG_IC(7), VKG_IC(1), s + 1, wb);
-    post(VKG_IC(7), VKG_IC(1), s + 1, wb, wa);
-    pre(VKG_IC(6), VKG_IC(2), s + 2, wa);
-    post(VKG_IC(6), VKG_IC(2), s + 2, wa, wb);
-    pre(VKG_IC(5), VKG_IC(3), s + 3, wb);
-    post(VKG_IC(5), VKG_IC(3), s + 3, wb, wa);
-    pre(VKG_IC(4), VKG_IC(0), s + 4, wa);
-    post(VKG_IC(4), VKG_IC(0), s + 4, wa, wb);
-    pre(VKG_IC(3), VKG_IC(1), s + 5, wb);
-    post(VKG_IC(3), VKG_IC(1), s + 5, wb, wa);
-    pre(VKG_IC(2), VKG_IC(2), s + 6, wa);
-    post(VKG_IC(2), VKG_IC(2), s + 6, wa, wb);
-    pre(VKG_IC(1), VKG_IC(3), s + 7, wb);
-    last_rows(wb);
-    if constexpr (STAMP) {
-        unsigned long t_c1, t_r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c1), "=s"(t_r1)::"memory");
-        if (tid == 0) {
-            unsigned long *o = p.stamps + (long)bid * 4;
-            o[0] = t_c1 - t_c0;
-            o[1] = t_r1 - t_r0;
-            o[2] = S;
-            o[3] = t_r1;
-        }
-    }
-#undef VKG_DSR
-#undef VKG_DSRX
-#undef VKG_MF
-#undef VKG_ROW
-#undef VKG_WAIT2
-#undef VKG_NONE
-#undef VKG_SB
-#undef VKG_IC
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2])::"memory");   // (as after a tile boundary: see below)
 
-    // ---- epilogue: (acc + bias) (+ residual) (ReLU) -> f16, straight from the accumulator layout ----
-    // hipcc does not see the asm MFMAs as matrix instructions: left alone it starts reading accumulators (v_accvgpr_read for
-    // the epilogue, hoisted into the last stage) one instruction after the MFMA that produces their final value -- stale
-    // results, found by the bit-identity tests.  So every accumulator is RE-DEFINED by a fence statement that follows the last
-    // MFMA's 4 passes + write-back: nothing can read it earlier.
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    bool first_tile = true;
+    unsigned long ph_loop = 0, ph_epi = 0, ph_tiles = 0, ts = 0, ts_first = 0, te_last = 0, t_c0 = 0, t_r0 = 0;   // STAMP
+    if constexpr (STAMP) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_first)::"memory");
+    for (int tt = bid;;) {
+        const int nt = tt + (int)gridDim.x;
+        // (computed by scalar asm: left to hipcc, the flag lives as a lane mask and every branch on it costs a VALU pair -- which it
+        // places right behind the MFMAs of the K loop)
+        asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(has_next) : "s"(nt), "s"(total_tiles) : "scc");
+        // B = the workgroup's next tile; on its last tile the stream simply requests this tile's first stages once more (nobody
+        // reads them): the K loop and its tail then hold no run-time condition at all
+        setup_tile(has_next ? nt : tt, B);
+        // zero the accumulators HERE (pinned: hipcc otherwise sinks the zeroing to just before each accumulator's first asm MFMA and,
+        // not seeing a matrix instruction there, leaves out the wait states a v_accvgpr write needs before an MFMA reads it as SrcC)
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-        asm volatile("" : "+a"(acc[mi][0]), "+a"(acc[mi][1]), "+a"(acc[mi][2]), "+a"(acc[mi][3]), "+a"(acc[mi][4]), "+a"(acc[mi][5]),
-                     "+a"(acc[mi][6]), "+a"(acc[mi][7]));
-    auto epilogue = [&](auto res_c, auto relu_c, auto full_c) {
-        constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+        for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int qn = 0; qn < 4; ++qn) {
-            const int ch = n0 + wc * 128 + qn * 32 + g * 8;
-            const floatx4 b0 = *reinterpret_cast<const floatx4 *>(p.bias + ch), b1 = *reinterpret_cast<const floatx4 *>(p.bias + ch + 4);
-            half8 rr[8];
-            if constexpr (RES) {
+            for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) asm volatile("" : "+a"(acc[mi][ni]));
+        asm volatile("s_nop 7" ::: "memory");
+        if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c0), "=s"(t_r0)::"memory");
+
+        pre(VKG_IC(99), VKG_IC(0), 0, wa);
+        int s = 0;
+        steady = true;
+        for (; s + 8 <= S; s += 4) {           // four stages per iteration: the slots are compile-time constants
+            post(VKG_IC(99), VKG_IC(0), s, wa, wb);
+            pre(VKG_IC(99), VKG_IC(1), s + 1, wb);
+            post(VKG_IC(99), VKG_IC(1), s + 1, wb, wa);
+            pre(VKG_IC(99), VKG_IC(2), s + 2, wa);
+            post(VKG_IC(99), VKG_IC(2), s + 2, wa, wb);
+            pre(VKG_IC(99), VKG_IC(3), s + 3, wb);
+            post(VKG_IC(99), VKG_IC(3), s + 3, wb, wa);
+            pre(VKG_IC(99), VKG_IC(0), s + 4, wa);
+        }
+        steady = false;
+        // s == S - 4, its rows 0-4 done: the last four stages; the requests riding on their rows are the next tile's first stages,
+        // and the last POST reads the next tile's first fragments.
+        post(VKG_IC(4), VKG_IC(0), s, wa, wb);
+        pre(VKG_IC(3), VKG_IC(1), s + 1, wb);
+        post(VKG_IC(3), VKG_IC(1), s + 1, wb, wa);
+        pre(VKG_IC(2), VKG_IC(2), s + 2, wa);
+        post(VKG_IC(2), VKG_IC(2), s + 2, wa, wb);
+        pre(VKG_IC(1), VKG_IC(3), s + 3, wb);
+        post(VKG_IC(1), VKG_IC(3), s + 3, wb, wa);
+        // the epilogue is compiler-scheduled code: no hand-issued read may be in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2])::"memory");
+        if constexpr (STAMP) {
+            unsigned long t_c1, t_r1;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c1), "=s"(t_r1)::"memory");
+            if (tid == 0 && first_tile) {
+                unsigned long *o = p.stamps + (long)bid * 8;
+                o[0] = t_c1 - t_c0;
+                o[1] = t_r1 - t_r0;
+            }
+            ph_loop += t_r1 - t_r0;
+            ts = t_r1;
+            ph_tiles += 1;
+        }
+
+        // ---- epilogue: (acc + bias) (+ residual) (ReLU) -> f16, straight from the accumulator layout ----
+        // hipcc does not see the asm MFMAs as matrix instructions: left alone it starts reading accumulators (v_accvgpr_read for
+        // the epilogue, hoisted into the last stage) one instruction after the MFMA that produces their final value -- stale
+        // results, found by the bit-identity tests.  So every accumulator is RE-DEFINED by a fence statement that follows the last
+        // MFMA's 4 passes + write-back: nothing can read it earlier.
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            asm volatile("" : "+a"(acc[mi][0]), "+a"(acc[mi][1]), "+a"(acc[mi][2]), "+a"(acc[mi][3]), "+a"(acc[mi][4]), "+a"(acc[mi][5]),
+                         "+a"(acc[mi][6]), "+a"(acc[mi][7]));
+        // lane coordinates re-derived from an opaque copy of the thread index: nothing per-lane of the epilogue has to stay alive
+        // (or be spilled) across the K loop, whose register file is full
+        int etid = threadIdx.x;
+        asm volatile("" : "+v"(etid));
+        const int eg = (etid & 63) >> 4, ej = etid & 15;
+        const int em0 = A.m0, en0 = A.n0;
+        auto epilogue = [&](auto res_c, auto relu_c, auto full_c) {
+            constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int qn = 0; qn < 4; ++qn) {
+                const int ch = en0 + wc * 128 + qn * 32 + eg * 8;
+                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bias_lds + ch), b1 = *reinterpret_cast<const floatx4 *>(bias_lds + ch + 4);
+                half8 rr[8];
+                if constexpr (RES) {          // (these loads retire in order behind the next tile's requests: a layer with a residual waits for them)
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const long m = min(em0 + wr * 128 + mi * 16 + ej, p.M - 1);
+                        rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
+                    }
+                }
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
-                    const long m = min(m0 + wr * 128 + mi * 16 + j, p.M - 1);
-                    rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
+                    floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
+                    if constexpr (RES) {
+                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
+                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 4, 5, 6, 7), floatx4);
+                    }
+                    half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
+                    half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                    const long m = em0 + wr * 128 + mi * 16 + ej;
+                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
                 }
             }
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
-                if constexpr (RES) {
-                    x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
-                    x1 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 4, 5, 6, 7), floatx4);
-                }
-                half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
-                half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                const long m = m0 + wr * 128 + mi * 16 + j;
-                if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
-            }
+        };
+        const bool full = em0 + 256 <= p.M;
+        auto by_full = [&](auto r_, auto l_) {
+            if (full)
+                epilogue(r_, l_, std::true_type{});
+            else
+                epilogue(r_, l_, std::false_type{});
+        };
+        auto by_relu = [&](auto r_) {
+            if (p.relu)
+                by_full(r_, std::true_type{});
+            else
+                by_full(r_, std::false_type{});
+        };
+        if (p.res)
+            by_relu(std::true_type{});
+        else
+            by_relu(std::false_type{});
+        if constexpr (STAMP) {
+            unsigned long te;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te)::"memory");
+            ph_epi += te - ts;
+            te_last = te;
         }
-    };
-    const bool full = m0 + 256 <= p.M;
-    auto by_full = [&](auto r_, auto l_) {
-        if (full)
-            epilogue(r_, l_, std::true_type{});
-        else
-            epilogue(r_, l_, std::false_type{});
-    };
-    auto by_relu = [&](auto r_) {
-        if (p.relu)
-            by_full(r_, std::true_type{});
-        else
-            by_full(r_, std::false_type{});
-    };
-    if (p.res)
-        by_relu(std::true_type{});
-    else
-        by_relu(std::false_type{});
+        if (!has_next) break;
+        A = B;
+        tt = nt;
+        first_tile = false;
+    }       // tiles of this workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the requests that followed the last tile must have landed before the LDS is released
+    if constexpr (STAMP) {
+        if (tid == 0) {
+            unsigned long *o = p.stamps + (long)bid * 8;
+            o[2] = ts_first;
+            o[3] = te_last;
+            o[4] = 0;
+            o[5] = ph_loop;
+            o[6] = ph_epi;
+            o[7] = ph_tiles;
+        }
+    }
 }
 
 bool conv_gemm4_eligible(const ConvArgs &a) {
@@ -413,7 +459,7 @@ bool conv_gemm4_eligible(const ConvArgs &a) {
     const bool any_grid = v && v[0] == '2';
     if (a.stem || a.pool_part || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
-    if (a.Cout % 256 != 0 || a.ldy != a.Cout) return false;
+    if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cout > 8192) return false;      // (the bias rides behind the ring in LDS)
     const int cin2 = a.x2 ? a.Cin2 : 0;
     if (a.Cin % 32 != 0 || cin2 % 32 != 0 || (a.Cin + cin2) % 128 != 0 || a.Cin + cin2 < 1024) return false;   // groups of four 32-channel stages
     if (a.Cin * 2 >= 16384 || cin2 * 2 >= 16384) return false;         // the row pitch is a 14-bit descriptor stride
@@ -427,8 +473,8 @@ bool conv_gemm4_eligible(const ConvArgs &a) {
 int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
         attr_set = true;
     }
     const int cin2 = a.x2 ? a.Cin2 : 0;
@@ -460,35 +506,50 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     k.stamps = nullptr;
+    // persistent workgroups, one per CU; a multiple of 8 so that a workgroup's tiles (bid, bid + grid, ...) stay on its XCD
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        VK_CHECK_HIP(hipGetDevice(&dev));
+        VK_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    const int total_tiles = k.m_tiles * k.n_tiles;
+    const int grid_wgs = total_tiles < n_cu ? total_tiles : n_cu;
     if (const char *sf = getenv("VK_GEMM4_STAMPS")) {    // diagnostic: one stamped launch, 4 words per workgroup appended to the file
-        const int nwg = k.m_tiles * k.n_tiles;
-        const size_t nb = (size_t)nwg * 4 * sizeof(unsigned long);
+        const int nwg = grid_wgs;
+        const size_t nb = (size_t)nwg * 8 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
         const char *d = getenv("VK_GEMM4_DBG");
         switch (d ? atoi(d) : 0) {
 #define VKG_DBG_CASE(D_)                                                                                                   \
     case D_:                                                                                                               \
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM)); \
-        hipLaunchKernelGGL((conv_gemm4_kernel<true, D_>), dim3(nwg), dim3(256), G_SMEM, stream, k);                        \
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768)); \
+        hipLaunchKernelGGL((conv_gemm4_kernel<true, D_>), dim3(nwg), dim3(256), G_SMEM + a.Cout * 4, stream, k);                        \
         break;
             VKG_DBG_CASE(1) VKG_DBG_CASE(2) VKG_DBG_CASE(3) VKG_DBG_CASE(4) VKG_DBG_CASE(8) VKG_DBG_CASE(12) VKG_DBG_CASE(13) VKG_DBG_CASE(15)
 #undef VKG_DBG_CASE
-            default: hipLaunchKernelGGL(conv_gemm4_kernel<true>, dim3(nwg), dim3(256), G_SMEM, stream, k);
+            default: hipLaunchKernelGGL(conv_gemm4_kernel<true>, dim3(nwg), dim3(256), G_SMEM + a.Cout * 4, stream, k);
         }
         VK_CHECK_HIP(hipStreamSynchronize(stream));
-        std::vector<unsigned long> h((size_t)nwg * 4);
+        std::vector<unsigned long> h((size_t)nwg * 8);
         VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
         VK_CHECK_HIP(hipFree(k.stamps));
         if (FILE *f = fopen(sf, "a")) {
             fprintf(f, "# wg loop_cycles loop_realtime_ticks stages end_realtime\n");
-            for (int w = 0; w < nwg; ++w) fprintf(f, "%d %lu %lu %lu %lu\n", w, h[(size_t)w * 4], h[(size_t)w * 4 + 1], h[(size_t)w * 4 + 2], h[(size_t)w * 4 + 3]);
+            for (int w = 0; w < nwg; ++w) {
+                fprintf(f, "%d", w);
+                for (int i = 0; i < 8; ++i) fprintf(f, " %lu", h[(size_t)w * 8 + i]);
+                fprintf(f, "\n");
+            }
             fclose(f);
         }
     } else if (getenv("VK_GEMM4_DBG") && atoi(getenv("VK_GEMM4_DBG")) == 128) {      // bisect: builtin MFMAs
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM));
-        hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(k.m_tiles * k.n_tiles), dim3(256), G_SMEM, stream, k);
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
+        hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
     } else {
-        hipLaunchKernelGGL(conv_gemm4_kernel<false>, dim3(k.m_tiles * k.n_tiles), dim3(256), G_SMEM, stream, k);
+        hipLaunchKernelGGL(conv_gemm4_kernel<false>, dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
     }
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
