@@ -129,25 +129,27 @@ __global__ void maxpool3x3s2_kernel(const T *__restrict__ x, T *__restrict__ y, 
 }
 
 // ---------------------------------------------------------------------------
-// RoIPool, torchvision semantics (see oracle/tv_ops.c): one workgroup per (RoI, output row ph);
+// RoIPool, torchvision semantics (see oracle/tv_ops.c): one workgroup per (RoI, group of RPW output rows);
 // the bin geometry is wave-uniform, lanes run over (pw, 16-B channel chunk).
-template <typename T>
+template <typename T, int RPW>
 __global__ void roi_pool_kernel(const T *__restrict__ feat, const float *__restrict__ rois, T *__restrict__ out, int H,
                                 int W, int C, int P, float scale) {
     typedef typename V16<T>::type vec;
     constexpr int VN = V16<T>::N;
-    const int k = blockIdx.x / P, ph = blockIdx.x % P;
+    const int groups = (P + RPW - 1) / RPW;
+    const int k = blockIdx.x / groups, ph0 = (blockIdx.x % groups) * RPW;
     const float *r = rois + 5 * (long)k;
     const int b = (int)r[0];
     const int rsw = (int)roundf(r[1] * scale), rsh = (int)roundf(r[2] * scale);
     const int rew = (int)roundf(r[3] * scale), reh = (int)roundf(r[4] * scale);
     const int roi_w = max(rew - rsw + 1, 1), roi_h = max(reh - rsh + 1, 1);
     const float bin_h = (float)roi_h / (float)P, bin_w = (float)roi_w / (float)P;
+    const int cv = C / VN;
+    const T *fb = feat + (long)b * H * W * C;
+    for (int ph = ph0; ph < min(ph0 + RPW, P); ++ph) {
     int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
     hs = min(max(hs + rsh, 0), H);
     he = min(max(he + rsh, 0), H);
-    const int cv = C / VN;
-    const T *fb = feat + (long)b * H * W * C;
     T *ob = out + ((long)k * P + ph) * P * C;
     for (int i = threadIdx.x; i < P * cv; i += blockDim.x) {
         int pw = i / cv, c = i - pw * cv;
@@ -155,19 +157,30 @@ __global__ void roi_pool_kernel(const T *__restrict__ feat, const float *__restr
         ws = min(max(ws + rsw, 0), W);
         we = min(max(we + rsw, 0), W);
         const bool empty = (he <= hs) || (we <= ws);
-        float m[VN];
-#pragma unroll
-        for (int e = 0; e < VN; ++e) m[e] = empty ? 0.f : -FLT_MAX;
-        for (int h = hs; h < he; ++h)
-            for (int w = ws; w < we; ++w) {
-                vec v = reinterpret_cast<const vec *>(fb + ((long)h * W + w) * C)[c];
-#pragma unroll
-                for (int e = 0; e < VN; ++e) m[e] = ((float)v[e] > m[e]) ? (float)v[e] : m[e];
-            }
         vec o;
+        if constexpr (sizeof(T) == 2) {
+            // f16: the maximum taken on the packed halves (v_pk_max_f16: 4 instructions per 16-byte load instead of 24 for
+            // convert / compare / select per element); same value as the fp32 form: a NaN never wins, an all-NaN bin gives -inf
+            // (what -FLT_MAX rounds to)
 #pragma unroll
-        for (int e = 0; e < VN; ++e) o[e] = (T)m[e];
+            for (int e = 0; e < VN; ++e) o[e] = empty ? (T)0.f : (T)(-__builtin_inff());
+            for (int h = hs; h < he; ++h)
+                for (int w = ws; w < we; ++w) o = __builtin_elementwise_max(o, reinterpret_cast<const vec *>(fb + ((long)h * W + w) * C)[c]);
+        } else {
+            float m[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) m[e] = empty ? 0.f : -FLT_MAX;
+            for (int h = hs; h < he; ++h)
+                for (int w = ws; w < we; ++w) {
+                    vec v = reinterpret_cast<const vec *>(fb + ((long)h * W + w) * C)[c];
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) m[e] = ((float)v[e] > m[e]) ? (float)v[e] : m[e];
+                }
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (T)m[e];
+        }
         reinterpret_cast<vec *>(ob + (long)pw * C)[c] = o;
+    }
     }
 }
 
@@ -315,10 +328,10 @@ int vk_roi_pool(const void *feat, int N, int H, int W, int C, const float *rois,
     if (K == 0) return VK_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dt == VK_F16)
-        hipLaunchKernelGGL(roi_pool_kernel<_Float16>, dim3(K * P), dim3(256), 0, s, (const _Float16 *)feat, rois,
+        hipLaunchKernelGGL((roi_pool_kernel<_Float16, 1>), dim3(K * P), dim3(256), 0, s, (const _Float16 *)feat, rois,
                            (_Float16 *)out, H, W, C, P, spatial_scale);
     else
-        hipLaunchKernelGGL(roi_pool_kernel<float>, dim3(K * P), dim3(256), 0, s, (const float *)feat, rois, (float *)out,
+        hipLaunchKernelGGL((roi_pool_kernel<float, 1>), dim3(K * P), dim3(256), 0, s, (const float *)feat, rois, (float *)out,
                            H, W, C, P, spatial_scale);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
