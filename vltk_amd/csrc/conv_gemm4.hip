@@ -51,14 +51,11 @@ constexpr int G_XB = 256 * G_ROWB;           // 16 KiB
 constexpr int G_SLOT = 2 * G_XB;             // 32 KiB
 constexpr int G_SMEM = G_NSLOT * G_SLOT;     // 128 KiB (the ring; the layer's bias, Cout x 4 B, sits behind it)
 
-#define VKG_GLDS16(gptr, lptr)                                                                         \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
-                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
-
 // STAMP: diagnostic build (VK_GEMM4_STAMPS=<file>): wave 0 stamps s_memtime / s_memrealtime around the first tile's K loop and
 // sums the phases of all its tiles into a buffer nothing else reads (tools/gemm4_stamps.py); never used by the product path
 // DBG (STAMP builds, timing only, WRONG results; VK_GEMM4_DBG): 1 = no LDS-DMA in the steady state, 2 = no stage barrier there,
-// 4 = no pixel-row fragment reads there, 8 = no weight fragment reads there
+// 4 = no pixel-row fragment reads there, 8 = no weight fragment reads there; 128 (plain build, correct results): MFMAs through the
+// builtin instead of asm -- the reference the asm form was debugged against (hipcc then shuffles accumulators inside the loop)
 struct Gemm4Tile {                      // what depends on the tile: origin, the lane's row indices, the three descriptors
     int m0, n0;
     unsigned xi[4];
