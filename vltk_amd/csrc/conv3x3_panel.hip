@@ -19,7 +19,9 @@
 //     counted lgkmcnt, counted vmcnt (the count depends only on the tap index: compile-time).
 //   * same per-wave geometry (2x4 waves, 128x64 per wave, 16x16x32 f16 MFMA) and the same LDS-staged
 //     whole-row epilogue as conv_mfma256.hip.
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "vk_common.h"
 
@@ -27,6 +29,7 @@ namespace vk {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 struct PanelK {
@@ -42,6 +45,7 @@ struct PanelK {
     int wrow_bytes;           // 9 * Cin * 2
     int relu;
     int m_tiles, n_tiles;
+    unsigned long *stamps;    // DBG & 4 builds: 4 words per workgroup
 };
 
 constexpr int P_NW = 6;                     // weight ring slots
@@ -78,7 +82,8 @@ __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// DBG: timing-only diagnostic builds (VK_CONV256_DBG): 1 = no tap-validity masking (WRONG results)
+// DBG: diagnostic builds: 1 = no tap-validity masking (VK_CONV256_DBG=1; timing only, WRONG results); 4 = stamps around the K loop
+// and the whole workgroup (VK_PANEL_STAMPS=<file>, tools/panel_stamps.py)
 // TAG 1: second symbol for launches of the two-stream backbone section (see conv_mfma_duo.hip)
 template <int PP, int DBG, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     constexpr int WBASE = 2 * PBYTES;
 
     const int bid = blockIdx.x, nwg = gridDim.x;
+    unsigned long st_k0 = 0;
+    if constexpr (DBG & 4) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k0)::"memory");
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int n_tile = t_ % p.n_tiles, m_tile = t_ / p.n_tiles;
@@ -298,6 +305,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     }
     vm_wait<2 * (P_NW - 1)>();
     asm volatile("s_barrier" ::: "memory");
+    unsigned long st_c0 = 0, st_r0 = 0;
+    if constexpr (DBG & 4) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0)::"memory");
     unsigned xa = x_addr_of(0, 0), xan = 0;
     VKP_READ_W(wa, 0u);
     VKP_DSR(xw[0], xa, 0);
@@ -327,6 +336,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         VKP_MMA_ROW(6, xw[2], wb, tm);
         VKP_MMA_ROW(7, xw[3], wb, tm);
     }
+    unsigned long st_c1 = 0, st_r1 = 0;
+    if constexpr (DBG & 4) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1)::"memory");
 #undef VKP_UNIT
 #undef VKP_IC
 #undef VKP_DSR
@@ -335,7 +346,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
 #undef VKP_READ_W
 #undef VKP_SB
 
-    // ---- epilogue (as conv_mfma256.hip): + bias (+ residual)(ReLU) through LDS, whole 512-B rows ----
+    // ---- epilogue: + bias (+ residual)(ReLU) -> f16 ----
+    // DIRECT (the default since round 2): straight from the accumulator layout -- a lane owns 8 consecutive channels of a pixel
+    // (16-byte stores, 64 B per pixel row and instruction), specialised on residual / ReLU / ragged tile like conv_ws.hip; same
+    // arithmetic, same bits.  DBG & 8: the first form, through LDS in two 128-row halves so that HBM sees whole 512-B rows
+    // (two barriers more, 64 ds_write_b128 + 32 ds_read_b128 per thread and tile).
+    if constexpr (!(DBG & 8)) {
+        auto epilogue = [&](auto res_c, auto relu_c, auto full_c) {
+            constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                const int ch = n0 + wc * 64 + qn * 32 + g * 8;
+                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(p.bias + ch), b1 = *reinterpret_cast<const floatx4 *>(p.bias + ch + 4);
+                half8 rr[8];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const long m = min(m0 + wr * 128 + mi * 16 + j, p.M - 1);
+                        rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
+                    if constexpr (RES) {
+                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
+                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 4, 5, 6, 7), floatx4);
+                    }
+                    half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
+                    half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
+                    const long m = m0 + wr * 128 + mi * 16 + j;
+                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
+                }
+            }
+        };
+        const bool full = m0 + 256 <= p.M;
+        auto by_full = [&](auto r_, auto l_) {
+            if (full)
+                epilogue(r_, l_, std::true_type{});
+            else
+                epilogue(r_, l_, std::false_type{});
+        };
+        auto by_relu = [&](auto r_) {
+            if (p.relu)
+                by_full(r_, std::true_type{});
+            else
+                by_full(r_, std::false_type{});
+        };
+        if (p.res)
+            by_relu(std::true_type{});
+        else
+            by_relu(std::false_type{});
+    } else {
     asm volatile("s_barrier" ::: "memory");
     floatx4 *stg = reinterpret_cast<floatx4 *>(smem);
     auto load_res = [&](int h, half8 (&rr)[8]) {
@@ -399,6 +462,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     VKP_LDS_BARRIER();
     write_half(1, r0);
 #undef VKP_LDS_BARRIER
+    }
+    if constexpr (DBG & 4) {
+        unsigned long st_k1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k1)::"memory");
+        if (threadIdx.x == 0) {
+            unsigned long *o = p.stamps + (long)bid * 4;
+            o[0] = st_c1 - st_c0;       // K loop, core cycles
+            o[1] = st_r1 - st_r0;       // K loop, 10 ns ticks
+            o[2] = st_k1 - st_k0;       // whole workgroup, 10 ns ticks
+            o[3] = st_r0 - st_k0;       // start .. K loop start
+        }
+    }
 }
 
 static int panel_pp(const ConvArgs &a) {
@@ -465,7 +540,27 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     }
     const dim3 grid(k.m_tiles * k.n_tiles), block(512);
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
-    if (panel_pp(a) == 3 && dbg == 1)
+    k.stamps = nullptr;
+    if (const char *sf = getenv("VK_PANEL_STAMPS"); sf && panel_pp(a) == 3) {   // diagnostic: one stamped launch (halo-64 build), 4 words per workgroup appended to the file
+        const size_t nb = (size_t)grid.x * 4 * sizeof(unsigned long);
+        VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 4>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+        VK_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long> h((size_t)grid.x * 4);
+        VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
+        VK_CHECK_HIP(hipFree(k.stamps));
+        if (FILE *f = fopen(sf, "a")) {
+            fprintf(f, "# wg k_loop_cycles k_loop_ticks workgroup_ticks ticks_before_k_loop (tick = 10 ns)\n");
+            for (unsigned w = 0; w < grid.x; ++w) fprintf(f, "%u %lu %lu %lu %lu\n", w, h[(size_t)w * 4], h[(size_t)w * 4 + 1], h[(size_t)w * 4 + 2], h[(size_t)w * 4 + 3]);
+            fclose(f);
+        }
+    } else if (panel_pp(a) == 3 && dbg == 8) {
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * 3 * 128 * 64 + P_NW * P_WSLOT));
+        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 8>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    } else if (panel_pp(a) == 3 && dbg == 1)
         hipLaunchKernelGGL((conv3x3_panel_kernel<3, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
     else if (panel_pp(a) == 3 && a.concurrent)
         hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
