@@ -344,8 +344,9 @@ def test_conv_gemm4_kernel_bit_identical(M_hw, cin, cout, res, relu, monkeypatch
     assert G.rel_err(ys[0], ref.half().float()) <= 1e-3
 
 
-@pytest.mark.parametrize("M,c1,c2,cout,relu", [(40000, 2048, 0, 512, True), (39917, 512, 1024, 2048, True), (70001, 1024, 0, 512, False)])
-def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, monkeypatch):
+@pytest.mark.parametrize("M,c1,c2,cout,relu,use_res", [(40000, 2048, 0, 512, True, False), (39917, 512, 1024, 2048, True, False),
+                                                        (70001, 1024, 0, 512, False, False), (33000, 2048, 0, 2048, True, True)])
+def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, use_res, monkeypatch):
     """conv_gemm4's persistent workgroups at sizes where each walks several tiles (one LDS ring across tile boundaries, the
     next tile's first stages requested by the previous tile's last ones, a ragged last tile): bit-identical to the ring kernel."""
     g = torch.Generator(device="cpu").manual_seed(M + c1)
@@ -355,6 +356,7 @@ def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, monkeypatch)
     w = (np.random.Generator(np.random.PCG64(M)).standard_normal((cout, K, 1, 1)) * (2.0 / K) ** 0.5).astype(np.float32)
     b = np.random.Generator(np.random.PCG64(M + 1)).standard_normal(cout).astype(np.float32)
     wd, bd = G.pack_conv(w, None, b, L.VK_F16)
+    res = (torch.randn((M, cout), generator=g) * 0.5).half().to(G.DEV) if use_res else None     # (ResNeXt's conv3: K = 2048 with the identity shortcut)
     ys = []
     for g4 in ("2", "0"):                                   # "2": also on grids below its usual floor (here 2 - 5 tiles per workgroup)
         monkeypatch.setenv("VK_CONV_GEMM4", g4)
@@ -362,7 +364,7 @@ def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, monkeypatch)
         if c2:
             L.call("vk_conv1x1_dual", G.P(x1), c1, G.P(x2), c2, M, G.P(wd), G.P(bd), None, G.P(y), cout, int(relu), G.stream())
         else:
-            L.call("vk_conv2d", G.P(x1), 1, 1, M, c1, G.P(wd), G.P(bd), None, G.P(y), cout, cout, 1, 1, 1, 0, 1, 1, int(relu), L.VK_F16,
+            L.call("vk_conv2d", G.P(x1), 1, 1, M, c1, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, 1, 1, 1, 0, 1, 1, int(relu), L.VK_F16,
                    L.VK_F16, G.stream())
         torch.cuda.synchronize()
         ys.append(y)
@@ -371,6 +373,8 @@ def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, monkeypatch)
     rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)]).to(G.DEV)
     xa = x1[rows].float() if not c2 else torch.cat([x1[rows], x2[rows]], dim=1).float()
     ref = xa @ torch.from_numpy(w.reshape(cout, K)).to(G.DEV).half().float().t() + torch.from_numpy(b).to(G.DEV)
+    if use_res:
+        ref = ref + res[rows].float()
     ref = (F.relu(ref) if relu else ref).half().float()
     assert G.rel_err(ys[0][rows].float().cpu(), ref.cpu()) <= 1e-3
 
