@@ -199,11 +199,12 @@ def test_conv1x1_dual(M, c1, c2, cout, res, monkeypatch):
 
 
 @pytest.mark.parametrize("N,HW,cin,cout", [(7, 196, 128, 256), (23, 196, 512, 512), (3, 255, 64, 256), (1, 128, 64, 256),
-                                           (301, 196, 512, 2048), (40, 130, 256, 1024)])
+                                           (301, 196, 512, 2048), (40, 130, 256, 1024), (9, 130, 512, 256)])
 def test_conv1x1_meanpool(N, HW, cin, cout, monkeypatch):
     """Last Res5 conv3 + residual + ReLU with `.mean(dim=[2,3])` (frcnn.py:1401) folded into the epilogue: equal to
-    conv -> f16 -> mean, bit-reproducible, and the same bits from the weight-stationary kernel (64-row tiles) and the
-    two-per-CU kernel (128-row tiles): the per-image sums are exact integers."""
+    conv -> f16 -> mean, bit-reproducible, and the same bits from the weight-stationary kernel (K = 512: 64-row tiles,
+    fp64 sums per image handed over with atomics) and the two-per-CU kernel (128-row tiles, integer sums per tile):
+    either way the per-image sums are exact."""
     g = _rng(N * HW)
     M = N * HW
     x = torch.from_numpy(g.standard_normal((M, cin)).astype(np.float32)).half()
@@ -241,6 +242,44 @@ def test_conv1x1_meanpool(N, HW, cin, cout, monkeypatch):
         L.call("vk_conv1x1_meanpool", G.P(xs), N - k, HW, cin, G.P(wp), G.P(bp), G.P(rs), cout, 1, G.P(out2), G.P(ws), nb, G.stream())
         torch.cuda.synchronize()
         assert torch.equal(out2.cpu(), outs[0][k:])
+
+
+@pytest.mark.parametrize("ws", ["1", "0"])
+def test_conv1x1_meanpool_nonfinite(ws, monkeypatch):
+    """An output that overflows f16 makes that image's mean of that channel NaN and touches nothing else -- on both
+    fused-mean kernels, including an image that shares its 64-row tile with the overflowing one."""
+    monkeypatch.setenv("VK_CONV_WS", ws)
+    N, HW, cin, cout = 12, 196, 512, 512
+    g = _rng(5)
+    M = N * HW
+    x = torch.from_numpy(g.standard_normal((M, cin)).astype(np.float32)).half()
+    r = torch.from_numpy(g.standard_normal((M, cout)).astype(np.float32)).half()
+    w = (g.standard_normal((cout, cin, 1, 1)) * (1.0 / cin) ** 0.5).astype(np.float32)
+    wp, bp = G.pack_conv(w, None, np.zeros(cout, np.float32), L.VK_F16)
+    nb = L.load().vk_conv1x1_meanpool_workspace_bytes(N, HW, cout)
+
+    xd = x.to(G.DEV)
+
+    def run(rr):
+        rd = rr.to(G.DEV)
+        ws_ = torch.empty(nb, dtype=torch.uint8, device=G.DEV)
+        out = torch.empty((N, cout), dtype=torch.float32, device=G.DEV)
+        L.call("vk_conv1x1_meanpool", G.P(xd), N, HW, cin, G.P(wp), G.P(bp), G.P(rd), cout, 1, G.P(out), G.P(ws_), nb, G.stream())
+        torch.cuda.synchronize()
+        return out.cpu()
+
+    clean = run(r)
+    assert bool(torch.isfinite(clean).all())
+    r2 = r.clone()
+    hits = [(3, 195, 17), (7, 0, 300), (7, 100, 301)]        # (image, row of the image, channel): last row, first row, middle
+    for n, row, c in hits:
+        r2[n * HW + row, c] = float("inf")
+    out = run(r2)
+    mask = torch.zeros((N, cout), dtype=torch.bool)
+    for n, _, c in hits:
+        mask[n, c] = True
+    assert bool(torch.isnan(out[mask]).all())
+    assert torch.equal(out[~mask], clean[~mask])
 
 
 @pytest.mark.parametrize("kernel", ["duo", "ring", "panel"])

@@ -370,8 +370,10 @@ static int launch_t(const ConvK &k, hipStream_t stream) {
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     const bool grouped = a.groups > 1;
     if (a.pool_part) {
-        VK_REQUIRE(conv_duo_pool_ok(a) && (!a.x2 || conv_duo_dual_ok(a)), VK_EINVAL,
+        VK_REQUIRE(conv_duo_pool_ok(a) && (!a.x2 || conv_duo_dual_ok(a)) && a.relu <= 1 && a.ldy == a.Cout, VK_EINVAL,
                    "conv: the fused-mean form is 1x1, stride 1, f16, Cout %% 256 == 0, Ho*Wo >= 128");
+        // per-image fp64 sums (conv_ws) or per-tile integer partials (two-per-CU kernel): launch_pool_finish asks the same function
+        if (conv_ws_pool_ok(a)) return launch_conv_ws(a, stream);
         return launch_conv_duo(a, stream);
     }
     if (a.x2) {

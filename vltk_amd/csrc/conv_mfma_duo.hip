@@ -539,8 +539,21 @@ __global__ void pool_finish_kernel(const int *__restrict__ part, int HoWo, int C
     }
 }
 
-int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream) {
-    hipLaunchKernelGGL(pool_finish_kernel, dim3(N), dim3(256), 0, stream, (const int *)part, HoWo, Cout, out);
+// out[n][c] = (exact fp64 sum of image n's rows, conv_ws's fused-mean form) / HoWo, rounded once; a non-finite sum -- some output
+// was not finite -- reads NaN, as above
+__global__ void pool_finish64_kernel(const double *__restrict__ sums, int HoWo, int Cout, float *__restrict__ out) {
+    const long n = blockIdx.x;
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+        const double sum = sums[n * Cout + c];
+        out[n * Cout + c] = __builtin_isfinite(sum) ? (float)(sum / (double)HoWo) : __builtin_nanf("");
+    }
+}
+
+int launch_pool_finish(const float *part, int N, int HoWo, int Cin, int Cout, bool dual, float *out, hipStream_t stream) {
+    if (conv_pool_sums_f64(N, HoWo, Cin, Cout, dual))
+        hipLaunchKernelGGL(pool_finish64_kernel, dim3(N), dim3(256), 0, stream, (const double *)part, HoWo, Cout, out);
+    else
+        hipLaunchKernelGGL(pool_finish_kernel, dim3(N), dim3(256), 0, stream, (const int *)part, HoWo, Cout, out);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }

@@ -29,6 +29,8 @@ namespace vk {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 struct WsK {
     const char *x;
@@ -42,6 +44,8 @@ struct WsK {
     int relu;
     int m_tiles, n_tiles;
     unsigned long *stamps;   // DBG & 32 builds only: 8 cycle sums per wave
+    double *pool;            // POOL builds: per-image column sums [M / HW][Cout] (exact in fp64), y is not written
+    int HW;                  // rows per image (>= 64: a 64-row tile touches at most two images)
 };
 
 #define VKW_GLDS16(gptr, lptr)                                                                         \
@@ -66,7 +70,13 @@ constexpr int WS_BM = 64;                    // rows per tile
 // (16 KiB stages, 7 slots, A = 1 / 2: 650 / 622 us vs 647 with the barrier on the 512 -> 2048 layer at M = 200 704; 8 KiB
 // stages, 15 slots, A = 4 / 6: 662 / 676 us).  The two waves of a SIMD would have to run a whole TILE apart for one's
 // epilogue to sit under the other's MFMAs, and the ring cannot hold that much (LDS: 64 rows x 512 channels = 64 KiB per tile).
-template <int KC, int NW, int DBG = 0>
+// POOL (K = 512, two waves per SIMD): the fused spatial mean of the last Res5 conv3 (`res5(x).mean(dim=[2,3])`, frcnn.py:1401).  The
+// f16 values a separate mean kernel would read back are summed per image in fp64 -- EXACTLY: an f16 is a multiple of 2^-24 below
+// 2^16, so a sum of up to 2^13 of them fits 53 bits whatever the order -- per lane over its 4 rows, across the 16 pixel lanes
+// through the wave's (then free) residual rows in LDS, and across tiles with global_atomic_add_f64; pool_finish64 divides and
+// rounds once.  Same bits as the two-per-CU kernel's integer sums; an image's mean does not depend on where the tile
+// boundaries fall.
+template <int KC, int NW, int DBG = 0, bool POOL = false>
 __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SCH = 128;                 // channels per ring stage
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     constexpr int PPW = WS_SLOT / 1024 / NW; // DMA pieces per wave and ring stage
     constexpr int RPW = 32 / NW;             // residual DMA pieces per wave and tile
     constexpr int NU = NI * 2;               // epilogue units (32 channels x 16 pixels) per wave
+    static_assert(!POOL || NW == 8, "the fused-mean epilogue is written for 32 channels per wave");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,6 +167,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     auto epilogue = [&](int it_, auto res_c, auto relu_c, auto full_c) {
         constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
         const long mbase = (long)(first + it_ * ML) * WS_BM;
+        // POOL: the tile's first image, the first row of its second one, and whether the tile reaches it (uniform)
+        const long img0 = POOL ? mbase / p.HW : 0;
+        const long m_split = (img0 + 1) * (POOL ? p.HW : 1);
+        const bool two_images = POOL && m_split < mbase + WS_BM && m_split < p.M;
+        unsigned *scr = reinterpret_cast<unsigned *>(res_lds);
+        int ln = lane;                       // POOL: lane coordinates re-derived here, so that the addresses below are computed
+        if constexpr (POOL) asm volatile("" : "+v"(ln));      // per tile instead of living in registers across the K loop
+        const int gp = ln >> 4, jp = ln & 15;
 #pragma unroll
         for (int u0 = 0; u0 < NU; u0 += 4) {                  // four units (32 channels x 64 pixels) at a time
             half8 rr[4];
@@ -183,7 +202,67 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
                 half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
                 const long m = mbase + pt * 16 + j;
-                if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
+                if constexpr (POOL) {
+                    // the lane's 4 channel pairs of row pt * 16 + j -> the wave's (consumed) residual rows, pair-major: dword
+                    // [pair g * 4 + k][(row + g * 16) & 63]; the rotation spreads the 64 lanes over the 64 banks
+                    if (!FULL && m >= p.M) o = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    const uintx4 ov = __builtin_bit_cast(uintx4, o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) scr[(gp * 4 + k) * 64 + ((pt * 16 + jp + gp * 16) & 63)] = ov[k];
+                } else {
+                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
+                }
+            }
+        }
+        if constexpr (POOL) {
+            // lane (pair = lane & 15, quarter = lane >> 4) adds rows quarter * 16 ... + 15 of its two channels in fp64 (exact),
+            // the four quarters meet through two lane exchanges, and lanes 0 ... 15 hand the tile's sums to the image's totals
+            const int pr = jp, q = gp;
+            const uintx4 *src = reinterpret_cast<const uintx4 *>(scr + pr * 64 + ((q + (pr >> 2)) & 3) * 16);
+            uintx4 v[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) v[c4] = src[c4];
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+            if (!two_images) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned d = v[r >> 2][r & 3];           // (a bit_cast straight from the vector element reads element 0)
+                    const half2v h = __builtin_bit_cast(half2v, d);
+                    a0 += (double)(float)h[0];
+                    a1 += (double)(float)h[1];
+                }
+            } else {
+                const int sloc = (int)(m_split - mbase);          // first row of the second image, 1 ... 63
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned d = v[r >> 2][r & 3];           // (a bit_cast straight from the vector element reads element 0)
+                    const half2v h = __builtin_bit_cast(half2v, d);
+                    const bool second = q * 16 + r >= sloc;
+                    const float lo = (float)h[0], hi = (float)h[1];
+                    a0 += (double)(second ? 0.f : lo);
+                    a1 += (double)(second ? 0.f : hi);
+                    b0 += (double)(second ? lo : 0.f);
+                    b1 += (double)(second ? hi : 0.f);
+                }
+            }
+            a0 += __shfl_xor(a0, 16);
+            a1 += __shfl_xor(a1, 16);
+            a0 += __shfl_xor(a0, 32);
+            a1 += __shfl_xor(a1, 32);
+            double *dst = p.pool + img0 * p.ldy + n0 + wave * WCH + pr * 2;
+            if (ln < 16) {
+                unsafeAtomicAdd(dst, a0);
+                unsafeAtomicAdd(dst + 1, a1);
+            }
+            if (two_images) {
+                b0 += __shfl_xor(b0, 16);
+                b1 += __shfl_xor(b1, 16);
+                b0 += __shfl_xor(b0, 32);
+                b1 += __shfl_xor(b1, 32);
+                if (ln < 16) {
+                    unsafeAtomicAdd(dst + p.ldy, b0);
+                    unsafeAtomicAdd(dst + p.ldy + 1, b1);
+                }
             }
         }
     };
@@ -315,10 +394,30 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     }
 }
 
+// The fused-mean form (a.pool_part set) runs here when K = 512 and the column blocks tile an XCD; otherwise on the two-per-CU
+// kernel.  The per-image fp64 sums (Cout x 8 B per image) live in the workspace that kernel sizes for its per-tile partials
+// (Cout x 16 B per 128 rows: larger from 128 rows per image on, which its own eligibility asks for).  Both sides of the
+// hand-over -- launch_conv and launch_pool_finish -- decide with this one function.
+bool conv_pool_sums_f64(long N, int HW, int Cin, int Cout, bool dual) {
+    const char *v = getenv("VK_CONV_WS");                // "0" disables (A/B switch and bit-identity tests; re-read per call)
+    if (v && v[0] == '0') return false;
+    const char *q = getenv("VK_WS_POOL");                // "0": the fused mean stays on the two-per-CU kernel
+    if (q && q[0] == '0') return false;
+    if (dual || Cin != 512 || Cout % 256 != 0 || 32 % (Cout / 256) != 0) return false;
+    const long M = N * HW;
+    return HW >= 128 && HW <= 8192 && M >= 8 * 128 && M < (1L << 31) - 128;
+}
+
+bool conv_ws_pool_ok(const ConvArgs &a) {
+    return a.pool_part && conv_duo_pool_ok(a) && a.relu <= 1 && a.ldy == a.Cout &&
+           conv_pool_sums_f64(a.N, a.Ho * a.Wo, a.Cin, a.Cout, a.x2 != nullptr);
+}
+
 bool conv_ws_eligible(const ConvArgs &a) {
     const char *v = getenv("VK_CONV_WS");                // "0" disables (A/B switch and bit-identity tests; re-read per call)
     if (v && v[0] == '0') return false;
-    if (a.stem || a.x2 || a.pool_part || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
+    if (a.pool_part) return conv_ws_pool_ok(a);
+    if (a.stem || a.x2 || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || (a.Cin != 128 && a.Cin != 256 && a.Cin != 512)) return false;
     const int nt = a.Cout / 256;
@@ -327,15 +426,15 @@ bool conv_ws_eligible(const ConvArgs &a) {
     return M >= 8 * 128 && M < (1L << 31) - 128;      // (a.Cin % 128 == 0: whole 128-channel ring stages)
 }
 
-template <int KC, int NW = 8, int DBG = 0>
+template <int KC, int NW = 8, int DBG = 0, bool POOL = false>
 static int launch_ws(const WsK &k, hipStream_t stream) {
     constexpr int smem = 6 * WS_BM * 256 + 4 * WS_BM * 128 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG>), dim3(256), dim3(NW * 64), smem, stream, k);
+    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG, POOL>), dim3(256), dim3(NW * 64), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
@@ -355,6 +454,8 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     k.m_tiles = (int)((M + WS_BM - 1) / WS_BM);
     k.n_tiles = a.Cout / 256;
     k.stamps = nullptr;
+    k.pool = (double *)a.pool_part;
+    k.HW = a.Ho * a.Wo;
 
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -364,6 +465,16 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     int st;
+    if (a.pool_part) {                                   // fused mean: zero the per-image sums, then the POOL build
+        VK_CHECK_HIP(hipMemsetAsync(k.pool, 0, (size_t)(M / k.HW) * a.Cout * sizeof(double), stream));
+        VK_TRY((launch_ws<16, 8, 0, true>(k, stream)));
+        if (tm) {
+            VK_CHECK_HIP(hipEventRecord(e1, stream));
+            tm->recs.push_back({a.concurrent ? 6 : 8, 2.0 * (double)M * a.Cout * a.Cin, e0, e1, (int)M, a.Cout, a.Cin, 1, 1,
+                                2.0 * ((double)M * a.Cin + (double)M * a.Cout * (a.res ? 1 : 0) + (double)a.Cout * a.Cin)});
+        }
+        return VK_OK;
+    }
     const char *nwv = getenv("VK_WS_WAVES");             // "4" / "8": A/B switch, re-read per call
     const int nw = nwv ? atoi(nwv) : 8;
     if (const char *sf = getenv("VK_WS_STAMPS")) {       // diagnostic: one stamped launch (K = 512), cycle sums appended to the file

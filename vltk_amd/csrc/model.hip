@@ -727,7 +727,7 @@ int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_pac
     a.relu = relu;
     a.dt = a.out_dt = VK_F16;
     VK_TRY(launch_conv(a, (hipStream_t)stream));
-    return launch_pool_finish((const float *)workspace, N, HW, cout, out_mean, (hipStream_t)stream);
+    return launch_pool_finish((const float *)workspace, N, HW, cin, cout, false, out_mean, (hipStream_t)stream);
 }
 
 static void stem_geom(int H, int W, int *H1, int *W1, int *Hp, int *Wp) {
@@ -1261,7 +1261,8 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
                 std::swap(a, b2);
             }
             if (p.pool_part)
-                VK_TRY(launch_pool_finish(pp, nb, hh * ww, h->res5_c, p.feat + (size_t)(k0 + n0) * h->res5_c, hs));
+                VK_TRY(launch_pool_finish(pp, nb, hh * ww, h->res5.back().conv3.cin, h->res5_c, h->res5.back().fused_shortcut,
+                                          p.feat + (size_t)(k0 + n0) * h->res5_c, hs));
         }
         if (split) {
             VK_CHECK_HIP(hipEventRecord(h->ev_join, h->side));

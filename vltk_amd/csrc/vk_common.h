@@ -91,7 +91,9 @@ int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
 bool conv_duo_pool_ok(const ConvArgs &a);                 // fused-mean form (pool_part set)
 size_t conv_duo_pool_part_bytes(long M, int Cout);
-int launch_pool_finish(const float *part, int N, int HoWo, int Cout, float *out, hipStream_t stream);                 // the dual-source form has no other kernel
+bool conv_pool_sums_f64(long N, int HW, int Cin, int Cout, bool dual);   // which form the fused mean's workspace holds (conv_ws.hip)
+bool conv_ws_pool_ok(const ConvArgs &a);
+int launch_pool_finish(const float *part, int N, int HoWo, int Cin, int Cout, bool dual, float *out, hipStream_t stream);
 
 // optional per-launch event timing (set by vk_forward when enabled; thread-local)
 struct KernelTimer {
