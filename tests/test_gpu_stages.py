@@ -57,6 +57,7 @@ CONV_CASES = [
     ("panel_wide", 1, 18, 84, 192, 256, 3, 1, 1, 1, False, False),
     ("panel_wide_d1", 2, 30, 100, 128, 256, 3, 1, 1, 1, True, True),
     ("panel_tiny", 1, 14, 14, 128, 256, 3, 1, 2, 2, False, True),      # M = 196 < one tile (last RoI chunk of a batch)
+    ("panel_res4", 1, 50, 84, 128, 256, 3, 1, 1, 1, True, True),       # one 800 x 1333 image at res4: 4200 px, reach 85 (halo 112 / 128)
     # two-workgroups-per-CU 1x1 kernel (128x256 tiles, 3-slot ring): stage counts 2, 4, 6, 10, 16 (prologue-only,
     # tail-only and steady-state paths), an edge tile, stride 2, with and without residual / ReLU
     ("duo_s2", 3, 24, 24, 64, 256, 1, 1, 0, 1, False, False),
@@ -95,6 +96,12 @@ def test_conv(case, dt, monkeypatch):
     tol = 1e-3 if dt == L.VK_F16 else 2e-5
     assert G.rel_err(y, ref) <= tol
     if case[0].startswith("panel_") and dt == L.VK_F16:
+        # 256- and 288-pixel tiles (8 / 9 row tiles per wave; the launcher picks by grid rounds) give the same bits
+        monkeypatch.setenv("VK_PANEL_MI", "9")
+        y9 = G.conv2d(x, w, bn=bn, residual_nchw=res, stride=stride, pad=pad, dil=dil, relu=relu, dt=dt)
+        monkeypatch.setenv("VK_PANEL_MI", "8")
+        y8 = G.conv2d(x, w, bn=bn, residual_nchw=res, stride=stride, pad=pad, dil=dil, relu=relu, dt=dt)
+        assert torch.equal(y8, y9) and torch.equal(y, y8)
         # the panel kernel's epilogue straight from the accumulators against its first form through LDS (halo-64 build: VK_CONV256_DBG=8)
         monkeypatch.setenv("VK_CONV256_DBG", "8")
         assert torch.equal(y, G.conv2d(x, w, bn=bn, residual_nchw=res, stride=stride, pad=pad, dil=dil, relu=relu, dt=dt))

@@ -85,11 +85,18 @@ __device__ __forceinline__ void vm_wait() {
 // DBG: diagnostic builds: 1 = no tap-validity masking (VK_CONV256_DBG=1; timing only, WRONG results); 4 = stamps around the K loop
 // and the whole workgroup (VK_PANEL_STAMPS=<file>, tools/panel_stamps.py)
 // TAG 1: second symbol for launches of the two-stream backbone section (see conv_mfma_duo.hip)
-template <int PP, int DBG, int TAG = 0>
+// MI: 16-pixel row tiles per wave: 8 (256-pixel tiles) or 9 (288-pixel tiles, halo 48 / 112).  Rows are independent, so the tile
+// height does not change a bit of the output; it changes how many rounds a grid takes (res4 at 32 x 800 x 1333: 525 tiles of 256
+// = 2.05 rounds on 256 CUs, paid as 3; 467 tiles of 288 = 1.82 rounds, paid as 2 x 9/8), and a step carries 36 instead of 32
+// MFMAs per wave over the same barrier, weight reads and DMA.  The launcher picks per launch.
+template <int PP, int DBG, int TAG = 0, int MI = 8>
 __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(MI == 8 || MI == 9, "8 or 9 row tiles per wave");
+    static_assert(MI == 8 || !(DBG & 8), "the LDS-staged epilogue is written for 128-row halves");
+    constexpr int TILE = 2 * MI * 16;             // pixels per tile
     constexpr int PROWS = PP * 128;               // panel rows
-    constexpr int HALO = (PROWS - 256) / 2;       // 64 or 128
+    constexpr int HALO = (PROWS - TILE) / 2;      // 64 or 128 (MI = 9: 48 or 112)
     constexpr int PBYTES = PROWS * 64;
     constexpr int WBASE = 2 * PBYTES;
 
@@ -99,18 +106,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int n_tile = t_ % p.n_tiles, m_tile = t_ / p.n_tiles;
-    const int m0 = m_tile * 256, n0 = n_tile * 256;
+    const int m0 = m_tile * TILE, n0 = n_tile * 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, j = lane & 15;
 
-    // ---- per-lane tap validity of its 8 fragment pixels (rows wr*128 + mi*16 + j): bit (tap*8 + mi) ----
-    unsigned vm0 = 0, vm1 = 0, vm2 = 0;           // taps 0-3 | 4-7 | 8
+    // ---- per-lane tap validity of its MI fragment pixels (rows wr*MI*16 + mi*16 + j): bit ((tap % 3) * 9 + mi) of word tap / 3 ----
+    unsigned vm0 = 0, vm1 = 0, vm2 = 0;           // taps 0-2 | 3-5 | 6-8
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + wr * 128 + mi * 16 + j;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wr * (MI * 16) + mi * 16 + j;
         if (m < p.M) {
             const int n_img = m / p.HW;
             const int rem = m - n_img * p.HW;
@@ -119,12 +126,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
             for (int tap = 0; tap < 9; ++tap) {
                 const int hi = ho + (tap / 3 - 1) * p.dil, wi = wo + (tap % 3 - 1) * p.dil;
                 const unsigned ok = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? 1u : 0u;
-                if (tap < 4)
-                    vm0 |= ok << (tap * 8 + mi);
-                else if (tap < 8)
-                    vm1 |= ok << ((tap - 4) * 8 + mi);
+                if (tap < 3)
+                    vm0 |= ok << (tap * 9 + mi);
+                else if (tap < 6)
+                    vm1 |= ok << ((tap - 3) * 9 + mi);
                 else
-                    vm2 |= ok << mi;
+                    vm2 |= ok << ((tap - 6) * 9 + mi);
             }
         }
     }
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         const int wrow = wc * 64 + (j >> 2) * 8 + par * 4 + (j & 3);
         w_a[par] = lds0 + WBASE + wrow * 64 + ((g ^ ((-(wrow >> 2)) & 3)) << 4);
     }
-    const int jbase = HALO + wr * 128 + j;                    // panel row of fragment pixel mi = 0 at zero shift
+    const int jbase = HALO + wr * (MI * 16) + j;              // panel row of fragment pixel mi = 0 at zero shift
     auto x_addr_of = [&](int parity, int tap) -> unsigned {   // byte address of fragment row mi = 0 (panel `parity`, tap)
         const int shift = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.dil;
         int jb = jbase;
@@ -169,16 +176,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         return lds0 + parity * PBYTES + (rb << 6) + ((g ^ ((-(rb >> 2)) & 3)) << 4);
     };
 
-    floatx4 acc[8][4];
+    floatx4 acc[MI][4];
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 wa[4], wb[4], xw[4];
+    half8 wa[4], wb[4], xw[MI == 9 ? 5 : 4];      // (MI = 9: row tile 8 has a fragment register of its own)
     const int CS = p.cstages;
 
 #define VKP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define VKP_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
+#define VKP_WAIT4(reg) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(reg))
 #define VKP_SB() __builtin_amdgcn_sched_barrier(0)
     // zero a fragment whose pixel is outside the image for this tap (4 v_cndmask), then 4 MFMAs
 #define VKP_MMA_ROW(MI, XR, WF, TM)                                                                  \
@@ -223,9 +231,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         constexpr int J = decltype(j_c)::value;
         // opaque copy of the mask word BEFORE the shift: otherwise hipcc hoists either the 72 (tap, row-tile)
         // lane masks (SGPR pairs) or the 9 shifted words out of the loop and spills them
-        unsigned tw = J < 4 ? vm0 : (J < 8 ? vm1 : vm2);
+        unsigned tw = J < 3 ? vm0 : (J < 6 ? vm1 : vm2);
         asm volatile("" : "+v"(tw));
-        return tw >> ((J & 3) * 8);
+        return tw >> ((J % 3) * 9);
     };
     auto pre = [&](auto last_c, auto odd_c, auto j_c, unsigned xa, unsigned &xa_next, const half8 (&wcur)[4]) {
         constexpr bool LAST = decltype(last_c)::value;
@@ -239,8 +247,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         VKP_DSR(xw[0], xa, 4096); VKP_WAIT3(xw[1]); VKP_SB(); VKP_MMA_ROW(1, xw[1], wcur, tm); VKP_SB();
         VKP_DSR(xw[1], xa, 5120); VKP_WAIT3(xw[2]); VKP_SB(); VKP_MMA_ROW(2, xw[2], wcur, tm); VKP_SB();
         VKP_DSR(xw[2], xa, 6144); VKP_WAIT3(xw[3]); VKP_SB(); VKP_MMA_ROW(3, xw[3], wcur, tm); VKP_SB();
-        VKP_DSR(xw[3], xa, 7168); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+        if constexpr (MI == 9) {
+            VKP_DSR(xw[3], xa, 7168); VKP_DSR(xw[4], xa, 8192); VKP_WAIT4(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(xw[MI == 9 ? 4 : 3])::"memory");
+        } else {
+            VKP_DSR(xw[3], xa, 7168); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
+        }
         VKP_SB();
         if constexpr (has_next) {
             // vmcnt: everything older than the pieces issued in the last P_NW-2 steps has landed = weights of step
@@ -278,6 +291,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         VKP_SB();
         VKP_MMA_ROW(7, xw[3], wcur, tm);
         VKP_SB();
+        if constexpr (MI == 9) {
+            VKP_MMA_ROW(8, xw[MI == 9 ? 4 : 3], wcur, tm);
+            VKP_SB();
+        }
     };
     // u = 9*ODD + J numbers the 18 steps of a pair of stages; step u works from fragment set u % 2
     auto wset = [&](auto u_c) -> half8(&)[4] {
@@ -335,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         VKP_MMA_ROW(5, xw[1], wb, tm);
         VKP_MMA_ROW(6, xw[2], wb, tm);
         VKP_MMA_ROW(7, xw[3], wb, tm);
+        if constexpr (MI == 9) VKP_MMA_ROW(8, xw[MI == 9 ? 4 : 3], wb, tm);
     }
     unsigned long st_c1 = 0, st_r1 = 0;
     if constexpr (DBG & 4) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1)::"memory");
@@ -342,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
 #undef VKP_IC
 #undef VKP_DSR
 #undef VKP_WAIT3
+#undef VKP_WAIT4
 #undef VKP_MMA_ROW
 #undef VKP_READ_W
 #undef VKP_SB
@@ -358,16 +377,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
             for (int qn = 0; qn < 2; ++qn) {
                 const int ch = n0 + wc * 64 + qn * 32 + g * 8;
                 const floatx4 b0 = *reinterpret_cast<const floatx4 *>(p.bias + ch), b1 = *reinterpret_cast<const floatx4 *>(p.bias + ch + 4);
-                half8 rr[8];
+                half8 rr[MI];
                 if constexpr (RES) {
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        const long m = min(m0 + wr * 128 + mi * 16 + j, p.M - 1);
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const long m = min(m0 + wr * (MI * 16) + mi * 16 + j, p.M - 1);
                         rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
                     }
                 }
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
+                for (int mi = 0; mi < MI; ++mi) {
                     floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
                     if constexpr (RES) {
                         x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
@@ -376,12 +395,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
                     half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
                     half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                     if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    const long m = m0 + wr * 128 + mi * 16 + j;
+                    const long m = m0 + wr * (MI * 16) + mi * 16 + j;
                     if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
                 }
             }
         };
-        const bool full = m0 + 256 <= p.M;
+        const bool full = m0 + TILE <= p.M;
         auto by_full = [&](auto r_, auto l_) {
             if (full)
                 epilogue(r_, l_, std::true_type{});
@@ -476,9 +495,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     }
 }
 
-static int panel_pp(const ConvArgs &a) {
+static int panel_pp(const ConvArgs &a, int mi = 8) {
     const int reach = a.dil * (a.W + 1);
+    if (mi == 9) return reach <= 48 ? 3 : (reach <= 112 ? 4 : 0);
     return reach <= 64 ? 3 : (reach <= 128 ? 4 : 0);
+}
+
+// 8 or 9 row tiles per wave (256- or 288-pixel tiles): whichever takes fewer MFMA rows over the rounds of the grid on this device.
+// VK_PANEL_MI=8 / 9 forces one where it is legal (A/B switch and bit-identity tests; re-read per call).
+static int panel_mi(const ConvArgs &a, long M) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 8;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    if (panel_pp(a, 9) == 0) return 8;
+    if (const char *v = getenv("VK_PANEL_MI")) {
+        if (v[0] == '8') return 8;
+        if (v[0] == '9') return 9;
+    }
+    // few rounds: count MFMA rows over the rounds (res4 of 32 images: 3 x 8 against 2 x 9).  Many rounds: the workgroups drift apart
+    // and the rounds blur; 36 MFMAs per barrier instead of 32 then win by ~1 % (measured on the Res5 conv2 grids, 14 rounds)
+    const long nt = a.Cout / 256;
+    const long n8 = ((M + 255) / 256 * nt + n_cu - 1) / n_cu, n9 = ((M + 287) / 288 * nt + n_cu - 1) / n_cu;
+    if (n8 > 4) return 9;
+    return n9 * 9 < n8 * 8 ? 9 : 8;
 }
 
 bool conv3x3_panel_eligible(const ConvArgs &a) {
@@ -495,20 +538,6 @@ bool conv3x3_panel_eligible(const ConvArgs &a) {
 }
 
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<4, 0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64 + P_NW * P_WSLOT));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 0, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 128 * 64 + P_NW * P_WSLOT));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<4, 0, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 128 * 64 + P_NW * P_WSLOT));
-        attr_set = true;
-    }
     PanelK k;
     k.x = (const char *)a.x;
     k.w = (const char *)a.w;
@@ -529,7 +558,8 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     k.cstages = a.Cin / 32;
     k.wrow_bytes = 9 * a.Cin * 2;
     k.relu = a.relu;
-    k.m_tiles = ceil_div(k.M, 256);
+    const int mi = panel_mi(a, M), pp = panel_pp(a, mi);
+    k.m_tiles = ceil_div(k.M, mi * 32);
     k.n_tiles = a.Cout / 256;
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -540,13 +570,25 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     }
     const dim3 grid(k.m_tiles * k.n_tiles), block(512);
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
+    const int smem = 2 * pp * 128 * 64 + P_NW * P_WSLOT;
     k.stamps = nullptr;
-    if (const char *sf = getenv("VK_PANEL_STAMPS"); sf && panel_pp(a) == 3) {   // diagnostic: one stamped launch (halo-64 build), 4 words per workgroup appended to the file
+#define VKP_LAUNCH(PP_, DBG_, TAG_, MI_)                                                                                                   \
+    do {                                                                                                                                   \
+        static bool attr_ = false;                                                                                                         \
+        if (!attr_) {                                                                                                                      \
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<PP_, DBG_, TAG_, MI_>),                  \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_ * 128 * 64 + P_NW * P_WSLOT));            \
+            attr_ = true;                                                                                                                  \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((conv3x3_panel_kernel<PP_, DBG_, TAG_, MI_>), grid, block, smem, stream, k);                                     \
+    } while (0)
+    if (const char *sf = getenv("VK_PANEL_STAMPS"); sf && pp == 3) {   // diagnostic: one stamped launch (halo-64 / 48 build), 4 words per workgroup appended to the file
         const size_t nb = (size_t)grid.x * 4 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         2 * 3 * 128 * 64 + P_NW * P_WSLOT));
-        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 4>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+        if (mi == 9)
+            VKP_LAUNCH(3, 4, 0, 9);
+        else
+            VKP_LAUNCH(3, 4, 0, 8);
         VK_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long> h((size_t)grid.x * 4);
         VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
@@ -556,20 +598,27 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
             for (unsigned w = 0; w < grid.x; ++w) fprintf(f, "%u %lu %lu %lu %lu\n", w, h[(size_t)w * 4], h[(size_t)w * 4 + 1], h[(size_t)w * 4 + 2], h[(size_t)w * 4 + 3]);
             fclose(f);
         }
-    } else if (panel_pp(a) == 3 && dbg == 8) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         2 * 3 * 128 * 64 + P_NW * P_WSLOT));
-        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 8>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
-    } else if (panel_pp(a) == 3 && dbg == 1)
-        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
-    else if (panel_pp(a) == 3 && a.concurrent)
-        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0, 1>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
-    else if (panel_pp(a) == 3)
-        hipLaunchKernelGGL((conv3x3_panel_kernel<3, 0>), grid, block, 2 * 3 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+    } else if (mi == 8 && pp == 3 && dbg == 8)
+        VKP_LAUNCH(3, 8, 0, 8);
+    else if (mi == 8 && pp == 3 && dbg == 1)
+        VKP_LAUNCH(3, 1, 0, 8);
+    else if (mi == 8 && pp == 3 && a.concurrent)
+        VKP_LAUNCH(3, 0, 1, 8);
+    else if (mi == 8 && pp == 3)
+        VKP_LAUNCH(3, 0, 0, 8);
+    else if (mi == 8 && a.concurrent)
+        VKP_LAUNCH(4, 0, 1, 8);
+    else if (mi == 8)
+        VKP_LAUNCH(4, 0, 0, 8);
+    else if (pp == 3 && a.concurrent)
+        VKP_LAUNCH(3, 0, 1, 9);
+    else if (pp == 3)
+        VKP_LAUNCH(3, 0, 0, 9);
     else if (a.concurrent)
-        hipLaunchKernelGGL((conv3x3_panel_kernel<4, 0, 1>), grid, block, 2 * 4 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+        VKP_LAUNCH(4, 0, 1, 9);
     else
-        hipLaunchKernelGGL((conv3x3_panel_kernel<4, 0>), grid, block, 2 * 4 * 128 * 64 + P_NW * P_WSLOT, stream, k);
+        VKP_LAUNCH(4, 0, 0, 9);
+#undef VKP_LAUNCH
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
