@@ -521,6 +521,37 @@ def test_maxpool(hw, caffe, dt):
     np.testing.assert_array_equal(G.to_nchw(y, dt).numpy(), ref.numpy())
 
 
+@pytest.mark.parametrize("caffe", [1, 0], ids=["caffe", "pad1"])
+@pytest.mark.parametrize("shape", [(1, 16, 16), (2, 37, 53), (3, 64, 64), (1, 123, 200), (2, 131, 67), (1, 800, 1333)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_stem_fused_bit_identical(shape, caffe, monkeypatch):
+    """The one-kernel stem (7x7 conv + BN + ReLU + max-pool out of LDS, csrc/stem_pool.hip) gives the bits of the
+    im2col conv followed by the pool kernel: same MFMA, same K order, same epilogue; tile edges, odd sizes, both pools."""
+    N, H, W = shape
+    g = _rng(H * 1000 + W)
+    x = torch.from_numpy((g.standard_normal((N, 3, H, W)) * 60.0).astype(np.float32))
+    w = (g.standard_normal((64, 3, 7, 7)) * 0.05).astype(np.float32)
+    bn = np.concatenate([g.uniform(0.5, 1.5, 64), g.standard_normal(64) * 0.1, g.standard_normal(64) * 0.1, g.uniform(0.5, 1.5, 64)]).astype(np.float32)
+    dt = L.VK_F16
+    wp = np.zeros(L.load().vk_packed_stem_bytes(64, dt), dtype=np.uint8)
+    bp = np.zeros(L.load().vk_packed_cout(64), dtype=np.float32)
+    L.call("vk_pack_stem_weight", np.ascontiguousarray(w).ctypes.data_as(C.c_void_p), bn.ctypes.data_as(C.c_void_p), 64, dt,
+           wp.ctypes.data_as(C.c_void_p), bp.ctypes.data_as(C.c_void_p))
+    wd, bd, xd = torch.from_numpy(wp).to(G.DEV), torch.from_numpy(bp).to(G.DEV), x.to(G.DEV)
+    ho, wo = C.c_int(), C.c_int()
+    L.load().vk_stem_out_hw(H, W, caffe, C.byref(ho), C.byref(wo))
+    outs = []
+    for fused in ("1", "0", "1"):
+        monkeypatch.setenv("VK_STEM_FUSED", fused)
+        ws = torch.empty(L.load().vk_stem_workspace_bytes(N, H, W, 64, dt), dtype=torch.uint8, device=G.DEV)
+        y = torch.full((N, ho.value, wo.value, 64), float("nan"), dtype=torch.float16, device=G.DEV)
+        L.call("vk_stem", G.P(xd), N, H, W, G.P(wd), G.P(bd), 64, caffe, G.P(y), dt, G.P(ws), ws.numel(), G.stream())
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+    assert bool(torch.isfinite(outs[0].float()).all())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
 def test_roi_pool(dt):
     """RoIPool incl. the edge cases torchvision defines: negative / oversize / degenerate boxes, .5 rounding."""

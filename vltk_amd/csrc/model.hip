@@ -747,6 +747,7 @@ static int stem_impl(const float *x, int N, int H, int W, const void *w, const f
     int H1, W1, Hp, Wp;
     stem_geom(H, W, &H1, &W1, &Hp, &Wp);
     VK_TRY(launch_stem_pack(x, img_pad, N, H, W, Hp, Wp, dt, s));
+    if (stem_pool_eligible(cout, dt)) return launch_stem_pool(img_pad, N, Hp, Wp, H1, W1, w, b, caffe, y, s);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = img_pad;

@@ -120,6 +120,9 @@ extern thread_local KernelTimer *g_timer;
 // ---- pool.hip ----
 int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s);
 int launch_maxpool(const void *x, void *y, int N, int H, int W, int C, int caffe, vk_dtype dt, hipStream_t s);
+bool stem_pool_eligible(int cout, vk_dtype dt);           // stem_pool.hip: 7x7 conv + BN + ReLU + max-pool as one kernel (f16, 64 channels)
+int launch_stem_pool(const void *x, int N, int Hp, int Wp, int H1, int W1, const void *w, const float *bias, int caffe, void *y,
+                     hipStream_t stream);
 
 // ---- roi_out.hip ----
 struct RoiFinalArgs {
