@@ -26,6 +26,7 @@ namespace vk {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct StemPoolK {
@@ -107,15 +108,11 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolK p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const floatx4 bq0 = *reinterpret_cast<const floatx4 *>(p.bias + q * 32 + gb), bq1 = *reinterpret_cast<const floatx4 *>(p.bias + q * 32 + gb + 4);
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = acc[2 * q][e] + bq0[e], b = acc[2 * q + 1][e] + bq1[e];
-                    a = a > 0.f ? a : 0.f;
-                    b = b > 0.f ? b : 0.f;
-                    o[e] = (_Float16)a;
-                    o[4 + e] = (_Float16)b;
-                }
+                // packed adds, v_cvt_pk_f16_f32, ReLU on the rounded halves (the same bits as max before rounding; NaN -> 0 either way)
+                const floatx4 x0 = acc[2 * q] + bq0, x1 = acc[2 * q + 1] + bq1;
+                const half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
+                half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
                 if (!valid) o = ninf;
                 *reinterpret_cast<half8 *>(st_lds + idx * 128 + (((q * 4 + g) ^ (idx & 7)) << 4)) = o;
             }
