@@ -46,11 +46,12 @@ constexpr int SP_NF = (SP_NPX + 15) / 16;               // 19 fragments of 16 pi
 constexpr int SP_IH = 2 * SP_SH + 5, SP_IW = 2 * SP_SW + 6;    // staged image: 23 x 72 pixels (kernel row reads run 8 pixels wide)
 constexpr int SP_IN_BYTES = SP_IH * SP_IW * 8;          // 13 248
 constexpr int SP_ST_BYTES = SP_NF * 16 * 128;           // 38 912
-constexpr int SP_SMEM = SP_IN_BYTES + SP_ST_BYTES;
+constexpr int SP_SMEM = SP_IN_BYTES + SP_ST_BYTES + 256;   // + the 64 bias values
 
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *in_lds = smem, *st_lds = smem + SP_IN_BYTES;
+    float *bias_lds = reinterpret_cast<float *>(smem + SP_IN_BYTES + SP_ST_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolK p) {
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) wf[ni][kh] = *reinterpret_cast<const half8 *>(p.w + row * 512 + kh * 64 + g * 16);
     }
+    if (tid < 64) bias_lds[tid] = p.bias[tid];       // read per fragment from LDS (16 values per lane: no registers beside the weights')
     const half8 ninf = {(_Float16)-INFINITY, (_Float16)-INFINITY, (_Float16)-INFINITY, (_Float16)-INFINITY,
                         (_Float16)-INFINITY, (_Float16)-INFINITY, (_Float16)-INFINITY, (_Float16)-INFINITY};
 
@@ -76,14 +78,24 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolK p) {
 
         int to = tid;                                    // opaque: the per-thread offsets of the copy and pool phases are recomputed
         asm volatile("" : "+v"(to));                     // per tile instead of living in registers beside the weights
-        // ---- the image under the tile -> LDS, 16 B (2 pixels) per request; outside the bordered image: zeros ----
-        for (int c = to; c < SP_IH * (SP_IW / 2); c += 256) {
+        // ---- the image under the tile -> LDS, 16 B (2 pixels) per request; outside the bordered image: zeros.  All of a thread's
+        // loads are issued before the first LDS write (one memory latency per tile, not four) ----
+        constexpr int NCH = SP_IH * (SP_IW / 2), NIT = (NCH + 255) / 256;
+        u32x4 cv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = to + 256 * it;
             const int r = c / (SP_IW / 2), k = c - r * (SP_IW / 2);
             const int row = ir0 + r, col = ic0 + 2 * k;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)row < (unsigned)p.Hp && (unsigned)col < (unsigned)p.Wp)
-                v = *reinterpret_cast<const u32x4 *>(p.x + (((long)n * p.Hp + row) * p.Wp + col) * 8);
-            *reinterpret_cast<u32x4 *>(in_lds + (r * SP_IW + 2 * k) * 8) = v;
+            cv[it] = u32x4{0u, 0u, 0u, 0u};
+            if (c < NCH && (unsigned)row < (unsigned)p.Hp && (unsigned)col < (unsigned)p.Wp)
+                cv[it] = *reinterpret_cast<const u32x4 *>(p.x + (((long)n * p.Hp + row) * p.Wp + col) * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = to + 256 * it;
+            const int r = c / (SP_IW / 2), k = c - r * (SP_IW / 2);
+            if (c < NCH) *reinterpret_cast<u32x4 *>(in_lds + (r * SP_IW + 2 * k) * 8) = cv[it];
         }
         __syncthreads();
 
@@ -103,11 +115,11 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(StemPoolK p) {
                 for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][kh], xf, acc[ni], 0, 0, 0);
             }
             const bool valid = idx < SP_NPX && (unsigned)(sr0 + r) < (unsigned)p.H1 && (unsigned)(sc0 + c) < (unsigned)p.W1;
-            int gb = g * 8;                              // opaque: the 16 bias values are re-read (L1) per fragment instead of held in
+            int gb = g * 8;                              // opaque: the 16 bias values are re-read (LDS) per fragment instead of held in
             asm volatile("" : "+v"(gb));                 // registers beside the 112 of the weights
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const floatx4 bq0 = *reinterpret_cast<const floatx4 *>(p.bias + q * 32 + gb), bq1 = *reinterpret_cast<const floatx4 *>(p.bias + q * 32 + gb + 4);
+                const floatx4 bq0 = *reinterpret_cast<const floatx4 *>(bias_lds + q * 32 + gb), bq1 = *reinterpret_cast<const floatx4 *>(bias_lds + q * 32 + gb + 4);
                 // packed adds, v_cvt_pk_f16_f32, ReLU on the rounded halves (the same bits as max before rounding; NaN -> 0 either way)
                 const floatx4 x0 = acc[2 * q] + bq0, x1 = acc[2 * q + 1] + bq1;
                 const half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
