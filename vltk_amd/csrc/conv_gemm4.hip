@@ -463,8 +463,10 @@ bool conv_gemm4_eligible(const ConvArgs &a) {
     if ((long)a.Cout * (a.Cin + cin2) * 2 >= (1L << 32)) return false;   // 32-bit weight offsets
     const long M = (long)a.N * a.Ho * a.Wo;
     if (M < 8 * 256 || M >= (1L << 31) - 256) return false;
-    // measured: ahead of the 8-wave kernels from about four rounds of tiles on (res4's conv1, 525 tiles: 117 vs 113 us)
-    return any_grid || ((M + 255) / 256) * (a.Cout / 256) >= 4 * 256;
+    // measured (end of round 2): ahead of the two-per-CU kernel from one tile per CU on -- res4's conv1, 1024 -> 256 at M = 134 400
+    // (525 tiles): 102.5 vs 113.7 us alone, backbone 14.49 -> 14.19 ms in the forward (four interleaved pairs); the first form of
+    // this kernel needed four rounds (117 vs 113 us)
+    return any_grid || ((M + 255) / 256) * (a.Cout / 256) >= 256;
 }
 
 int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
