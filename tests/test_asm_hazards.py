@@ -34,7 +34,7 @@ def test_no_inflight_register_use(src):
     res = chk.scan_file(os.path.join(chk.CSRC, src))
     assert res, "no kernels found"
     if src == "conv_gemm4.hip":      # its timing-only ablation builds (DBG != 0) replace fragment reads by dummies: not product code
-        res = {k: v for k, v in res.items() if "ELi0EEE" in k}
+        res = {k: v for k, v in res.items() if "ELi0ELi0EEE" in k or "ELi0ELi1EEE" in k}    # <STAMP, DBG = 0, TAG>
         assert res
     bad = {k: v[:3] for k, v in res.items() if v}
     assert not bad, bad
@@ -56,6 +56,6 @@ def test_gemm4_loop_has_no_compiler_valu():
     """conv_gemm4.hip writes its MFMAs as asm: between the first and the last of them the product build must hold no
     accumulator traffic and no compiler-generated VALU instruction (both were real bugs: see the kernel's comments)."""
     res = chk.scan_file(os.path.join(chk.CSRC, "conv_gemm4.hip"), scan=chk.scan_asm_mfma_region)
-    prod = {k: v for k, v in res.items() if "Lb0ELi0E" in k}
+    prod = {k: v for k, v in res.items() if "Lb0ELi0ELi" in k}     # <false, 0, TAG>
     assert prod, list(res)
     assert all(not v for v in prod.values()), {k: v[:4] for k, v in prod.items() if v}

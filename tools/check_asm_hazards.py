@@ -177,7 +177,7 @@ def main():
     for f in files:
         for name, found in scan_file(f).items():
             print(f"{os.path.basename(f)}  {name}: {len(found)} hazard(s)")
-            ablation = "conv_gemm4_kernel" in name and "ILb0ELi0EEE" not in name   # stamp / timing-only DBG builds (dummy reads): not product code
+            ablation = "conv_gemm4_kernel" in name and "ILb0ELi0ELi" not in name   # stamp / timing-only DBG builds (dummy reads): not product code
             for i, t, li in found[:0 if ablation else 6]:
                 print(f"    line +{i}: {t}    <- ds_read at +{li} still pending")
             bad += 0 if ablation else len(found)
@@ -186,7 +186,7 @@ def main():
                 print(f"{os.path.basename(f)}  {name}: {len(found)} compiler VALU / accumulator instruction(s) between asm MFMAs")
                 for i, t in found[:6]:
                     print(f"    +{i}: {t}")
-                if "ILb0ELi0EEE" in name:                   # stamp and ablation builds are not product code
+                if "ILb0ELi0ELi" in name:                   # stamp and ablation builds are not product code
                     bad += len(found)
     return 1 if bad else 0
 

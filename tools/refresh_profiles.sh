@@ -21,7 +21,7 @@ find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OU
 # two-stream backbone section carry other template arguments)
 python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_duo.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv3x3_panel_kernel<3, 0, 0, 9>" --json $OUT/${TAG}_pmc_panel.json --name conv3x3_panel_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
-python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_gemm4_kernel" --json $OUT/${TAG}_pmc_gemm4.json --name conv_gemm4_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_gemm4_kernel<false, 0, 0>" --json $OUT/${TAG}_pmc_gemm4.json --name conv_gemm4_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_ws_kernel" --json $OUT/${TAG}_pmc_ws.json --name conv_ws_kernel --batch 32 --proposals 300 --min-workgroups 200 >> $OUT/${TAG}_pmc_summary.txt
 python - <<PY
 import json

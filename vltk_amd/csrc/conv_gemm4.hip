@@ -62,7 +62,9 @@ struct Gemm4Tile {                      // what depends on the tile: origin, the
     __amdgpu_buffer_rsrc_t rx1, rx2, rw;
 };
 
-template <bool STAMP, int DBG = 0>
+// TAG 1: the same code under a second symbol for launches of the two-stream backbone section (res4's conv1 half-batches), so that
+// profilers list the launches that overlap another stream apart from the ones that run alone (see conv_mfma_duo.hip)
+template <bool STAMP, int DBG = 0, int TAG = 0>
 __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -547,6 +549,13 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     } else if (getenv("VK_GEMM4_DBG") && atoi(getenv("VK_GEMM4_DBG")) == 128) {      // bisect: builtin MFMAs
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
         hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
+    } else if (a.concurrent) {
+        static bool attr1 = false;
+        if (!attr1) {
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
+            attr1 = true;
+        }
+        hipLaunchKernelGGL((conv_gemm4_kernel<false, 0, 1>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
     } else {
         hipLaunchKernelGGL(conv_gemm4_kernel<false>, dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
     }
