@@ -391,7 +391,10 @@ def test_conv_gemm4_kernel_bit_identical(M_hw, cin, cout, res, relu, monkeypatch
 
 
 @pytest.mark.parametrize("M,c1,c2,cout,relu,use_res", [(40000, 2048, 0, 512, True, False), (39917, 512, 1024, 2048, True, False),
-                                                        (70001, 1024, 0, 512, False, False), (33000, 2048, 0, 2048, True, True)])
+                                                        (70001, 1024, 0, 512, False, False), (33000, 2048, 0, 2048, True, True),
+                                                        # res4's conv1 (full and half batch: 525 / 263 tiles), other grids of full rounds + a few tiles
+                                                        (67200, 1024, 0, 256, True, False), (134400, 1024, 0, 256, True, False),
+                                                        (66000, 512, 1024, 512, True, False), (66500, 2048, 0, 256, True, True)])
 def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, use_res, monkeypatch):
     """conv_gemm4's persistent workgroups at sizes where each walks several tiles (one LDS ring across tile boundaries, the
     next tile's first stages requested by the previous tile's last ones, a ragged last tile): bit-identical to the ring kernel."""
