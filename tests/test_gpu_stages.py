@@ -165,7 +165,7 @@ def test_conv3x3_blk_kernel(case, monkeypatch):
     assert G.rel_err(ys[0], ref) <= 1e-3
 
 
-@pytest.mark.parametrize("M,c1,c2,cout,res", [(1500, 64, 64, 256, False), (4000, 512, 1024, 512, False),
+@pytest.mark.parametrize("M,c1,c2,cout,res", [(1500, 64, 64, 256, False), (33403, 64, 64, 256, False), (9000, 64, 64, 512, True), (4000, 512, 1024, 512, False),
                                               (130, 128, 256, 256, True), (2600, 128, 192, 256, True),
                                               (2500, 512, 1024, 2048, False), (1030, 256, 768, 256, True)])
 def test_conv1x1_dual(M, c1, c2, cout, res, monkeypatch):
@@ -188,8 +188,9 @@ def test_conv1x1_dual(M, c1, c2, cout, res, monkeypatch):
     monkeypatch.setenv("VK_CONV_GEMM4", "2")                # the four-wave GEMM also on grids this small
     L.call("vk_conv1x1_dual", G.P(x1d), c1, G.P(x2d), c2, M, G.P(wcat), G.P(b1 + b2), G.P(rd), G.P(y), cout, 1, G.stream())
     torch.cuda.synchronize()
-    # the same layer on the other kernels that take it: four-wave GEMM (K >= 1024) -> ring kernel -> two-per-CU kernel
-    for off in (("VK_CONV_GEMM4",), ("VK_CONV_GEMM4", "VK_CONV256_DUAL")):
+    # the same layer on the other kernels that take it: weight-stationary kernel (64 + 64 channels) / four-wave GEMM (K >= 1024) ->
+    # ring kernel -> two-per-CU kernel
+    for off in (("VK_CONV_WS",), ("VK_CONV_WS", "VK_CONV_GEMM4"), ("VK_CONV_WS", "VK_CONV_GEMM4", "VK_CONV256_DUAL")):
         for k in off:
             monkeypatch.setenv(k, "0")
         y2 = torch.full_like(y, float("nan"))
@@ -338,11 +339,13 @@ def test_conv_1x1_kernels_bit_identical(monkeypatch):
 
 
 @pytest.mark.parametrize("M_hw,cin,cout,res", [((7, 50, 84), 256, 1024, True), ((200, 14, 14), 512, 2048, True), ((3, 37, 41), 128, 512, True),
-                                               ((200, 14, 14), 512, 512, False), ((1, 32, 33), 512, 256, True)])
+                                               ((200, 14, 14), 512, 512, False), ((1, 32, 33), 512, 256, True),
+                                               ((2, 100, 167), 64, 256, True), ((1, 33, 35), 64, 512, False)])
 def test_conv_ws_kernel_bit_identical(M_hw, cin, cout, res, monkeypatch):
     """conv_ws.hip (weight-stationary 1x1, K <= 512: weights in registers, pixels through an LDS-DMA ring that runs across
     tile boundaries) against the two-per-CU kernel on the same layer: bit-identical (same K order, same epilogue
-    arithmetic), with many tiles per workgroup, a ragged last tile and every stage count (2 / 4 / 8 per tile)."""
+    arithmetic), with many tiles per workgroup, a ragged last tile, every stage count (1 / 2 / 4 per tile) and both stage widths
+    (K = 64: 64-channel stages)."""
     N, H, W = M_hw
     g = _rng(cin * cout + N)
     x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))

@@ -377,6 +377,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         return launch_conv_duo(a, stream);
     }
     if (a.x2) {
+        if (conv_ws_eligible(a)) return launch_conv_ws(a, stream);           // 64 + 64 channels (res2's first conv3 + shortcut)
         if (conv_gemm4_eligible(a)) return launch_conv_gemm4(a, stream);
         if (conv256_dual_ok(a)) return launch_conv256(a, stream);
         VK_REQUIRE(conv_duo_dual_ok(a), VK_EINVAL,

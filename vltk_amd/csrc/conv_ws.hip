@@ -34,6 +34,7 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 struct WsK {
     const char *x;
+    const char *x2;          // DUAL builds: the second 64 channels of the K = 128 stage (conv3 + projection shortcut of res2)
     const char *w;
     const float *bias;
     const char *res;
@@ -76,10 +77,14 @@ constexpr int WS_BM = 64;                    // rows per tile
 // through the wave's (then free) residual rows in LDS, and across tiles with global_atomic_add_f64; pool_finish64 divides and
 // rounds once.  Same bits as the two-per-CU kernel's integer sums; an image's mean does not depend on where the tile
 // boundaries fall.
-template <int KC, int NW, int DBG = 0, bool POOL = false>
+// KC = 2 (K = 64: res2's conv3): ring stages of 64 channels (128-byte rows), one stage per tile.
+// DUAL (KC = 4): the 128-channel stage is [64 channels of x | 64 channels of x2] -- res2's first conv3 and its projection shortcut as
+// one GEMM (`out += shortcut`, frcnn.py:970-977; the weights hold the concatenated rows); a DMA lane picks its source by chunk.
+template <int KC, int NW, int DBG = 0, bool POOL = false, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SCH = 128;                 // channels per ring stage
+    static_assert(!DUAL || KC == 4, "two sources: 64 + 64 channels");
+    constexpr int SCH = KC == 2 ? 64 : 128;  // channels per ring stage
     constexpr int KSL = SCH / 32;            // MFMA K steps per stage
     constexpr int PITCH = SCH * 2;           // bytes per pixel row of a stage
     constexpr int WS_SLOT = WS_BM * PITCH;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int co = n0 + wave * WCH + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
-        const char *wr = p.w + (long)co * p.kbytes + g * 16;
+        const char *wr = p.w + (long)co * (DUAL ? 256 : p.kbytes) + g * 16;     // (DUAL: rows of 64 + 64 channels)
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) wf[ni][ks] = *reinterpret_cast<const half8 *>(wr + ks * 64);
     }
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     // (64-channel stages: 128-byte rows = whole cache lines, pieces of 8 rows, slot lane & 7 holding chunk slot ^ (row & 7))
     constexpr int LPR = PITCH / 16;          // lanes (16-byte slots) per row
     const int drow = lane / LPR, dslot = lane & (LPR - 1);
-    auto request = [&](int q_, int qlo = 0, int qhi = 16 / NW) {   // q_ = global stage index of this workgroup; pieces [qlo, qhi)
+    auto request = [&](int q_, int qlo = 0, int qhi = WS_BM * (KC == 2 ? 128 : 256) / 1024 / NW) {   // q_ = global stage index of this workgroup; pieces [qlo, qhi = PPW)
         const int it = q_ / SPT, st = q_ - it * SPT;
         const int m0 = (first + it * ML) * WS_BM;
         char *dst = smem + (q_ % WS_NS) * WS_SLOT + wave * PPW * 1024;
@@ -139,7 +144,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
         for (int q = qlo; q < qhi; ++q) {
             const int row = (wave * PPW + q) * (64 / LPR) + drow;
             const int m = min(m0 + row, p.M - 1);                             // rows past M are computed and dropped
-            VKW_GLDS16(p.x + (long)m * p.kbytes + st * PITCH + ((dslot ^ (row & (LPR - 1))) << 4), dst + q * 1024);
+            if constexpr (DUAL) {
+                const int c = dslot ^ (row & (LPR - 1));                          // chunk 0-7: x, 8-15: x2 (one stage per tile)
+                VKW_GLDS16((c < 8 ? p.x : p.x2) + (long)m * 128 + ((c & 7) << 4), dst + q * 1024);
+            } else {
+                VKW_GLDS16(p.x + (long)m * p.kbytes + st * PITCH + ((dslot ^ (row & (LPR - 1))) << 4), dst + q * 1024);
+            }
         }
     };
     for (int q_ = 0; q_ < WS_D && q_ < total; ++q_) request(q_);
@@ -417,24 +427,25 @@ bool conv_ws_eligible(const ConvArgs &a) {
     const char *v = getenv("VK_CONV_WS");                // "0" disables (A/B switch and bit-identity tests; re-read per call)
     if (v && v[0] == '0') return false;
     if (a.pool_part) return conv_ws_pool_ok(a);
-    if (a.stem || a.x2 || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
+    if (a.stem || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
     if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
-    if (a.Cout % 256 != 0 || a.ldy != a.Cout || (a.Cin != 128 && a.Cin != 256 && a.Cin != 512)) return false;
+    if (a.x2 && (a.Cin != 64 || a.Cin2 != 64)) return false;             // two sources: 64 + 64 channels only
+    if (a.Cout % 256 != 0 || a.ldy != a.Cout || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256 && a.Cin != 512)) return false;
     const int nt = a.Cout / 256;
     if (32 % nt != 0) return false;                      // column blocks must tile the 32 workgroups of an XCD
     const long M = (long)a.N * a.Ho * a.Wo;
     return M >= 8 * 128 && M < (1L << 31) - 128;      // (a.Cin % 128 == 0: whole 128-channel ring stages)
 }
 
-template <int KC, int NW = 8, int DBG = 0, bool POOL = false>
+template <int KC, int NW = 8, int DBG = 0, bool POOL = false, bool DUAL = false>
 static int launch_ws(const WsK &k, hipStream_t stream) {
     constexpr int smem = 6 * WS_BM * 256 + 4 * WS_BM * 128 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG, POOL, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG, POOL>), dim3(256), dim3(NW * 64), smem, stream, k);
+    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG, POOL, DUAL>), dim3(256), dim3(NW * 64), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
@@ -442,6 +453,7 @@ static int launch_ws(const WsK &k, hipStream_t stream) {
 int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     WsK k;
     k.x = (const char *)a.x;
+    k.x2 = (const char *)a.x2;
     k.w = (const char *)a.w;
     k.bias = a.bias;
     k.res = (const char *)a.res;
@@ -501,7 +513,11 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         const int dbg = d ? atoi(d) : 0;
 #define VKW_DBG_CASE(NW_, D_) \
     case D_: st = launch_ws<16, NW_, D_>(k, stream); break;
-        if (a.Cin == 128)
+        if (a.x2)
+            st = launch_ws<4, 8, 0, false, true>(k, stream);
+        else if (a.Cin == 64)
+            st = nw == 8 ? launch_ws<2, 8>(k, stream) : launch_ws<2, 4>(k, stream);
+        else if (a.Cin == 128)
             st = nw == 8 ? launch_ws<4, 8>(k, stream) : launch_ws<4, 4>(k, stream);
         else if (a.Cin == 256)
             st = nw == 8 ? launch_ws<8, 8>(k, stream) : launch_ws<8, 4>(k, stream);
@@ -523,8 +539,9 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     VK_TRY(st);
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));
-        tm->recs.push_back({a.concurrent ? 6 : 8, 2.0 * (double)M * a.Cout * a.Cin, e0, e1, (int)M, a.Cout, a.Cin, 1, 1,
-                            2.0 * ((double)M * a.Cin + (double)M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.Cin)});
+        const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
+        tm->recs.push_back({a.concurrent ? 6 : 8, 2.0 * (double)M * a.Cout * K, e0, e1, (int)M, a.Cout, K, 1, 1,
+                            2.0 * ((double)M * K + (double)M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * K)});
     }
     return VK_OK;
 }
