@@ -17,15 +17,14 @@ echo "pmc fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc/w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/${TAG}_pmc_w.log 2>&1
 echo "pmc write done"
 find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
-# HBM bytes per launch of the three kernels with the most GPU time (launches that run alone: the half-batch launches of the
+# HBM bytes per launch of the three kernels with the most GPU time (the two-per-CU kernel no longer has launches that run alone) (launches that run alone: the half-batch launches of the
 # two-stream backbone section carry other template arguments)
-python tools/pmc_summary.py $OUT/${TAG}_pmc "Lb0ELi0EEEvNS_4DuoKE" --json $OUT/${TAG}_pmc_duo.json --name conv_duo_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
-python tools/pmc_summary.py $OUT/${TAG}_pmc "conv3x3_panel_kernel<3, 0, 0, 9>" --json $OUT/${TAG}_pmc_panel.json --name conv3x3_panel_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/${TAG}_pmc "conv3x3_panel_kernel<3, 0, 0, 9>" --json $OUT/${TAG}_pmc_panel.json --name conv3x3_panel_kernel --batch 32 --proposals 300 > $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_gemm4_kernel<false, 0, 0>" --json $OUT/${TAG}_pmc_gemm4.json --name conv_gemm4_kernel --batch 32 --proposals 300 >> $OUT/${TAG}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/${TAG}_pmc "conv_ws_kernel" --json $OUT/${TAG}_pmc_ws.json --name conv_ws_kernel --batch 32 --proposals 300 --min-workgroups 200 >> $OUT/${TAG}_pmc_summary.txt
 python - <<PY
 import json
-ks = [json.load(open("$OUT/${TAG}_pmc_%s.json" % k)) for k in ("panel", "gemm4", "duo", "ws")]
+ks = [json.load(open("$OUT/${TAG}_pmc_%s.json" % k)) for k in ("panel", "gemm4", "ws")]
 json.dump({"batch": 32, "proposals": 300, "kernels": ks}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1)
 PY
 # keep only the summaries (the raw traces are large)
