@@ -365,6 +365,26 @@ def test_conv_ws_kernel_bit_identical(M_hw, cin, cout, res, monkeypatch):
     assert G.rel_err(ys[0], F.relu(ref).half().float()) <= 1e-3
 
 
+@pytest.mark.parametrize("M_hw,cin,cout,stride,relu", [((3, 100, 167), 256, 512, 2, False), ((5, 50, 84), 512, 1024, 2, False),
+                                                       ((2, 51, 85), 512, 256, 2, True), ((1, 67, 40), 256, 256, 3, True)])
+def test_conv_ws_strided_bit_identical(M_hw, cin, cout, stride, relu, monkeypatch):
+    """conv_ws.hip on strided 1x1 convs (the stride-2 projection shortcuts and first conv1s of res3 / res4, frcnn.py:934-941: the DMA
+    lane maps its output row to an input pixel) against the two-per-CU kernel: bit-identical, odd sizes, ragged tiles."""
+    N, H, W = M_hw
+    g = _rng(cin * cout + N + stride)
+    x = torch.from_numpy(g.standard_normal((N, cin, H, W)).astype(np.float32))
+    w = (g.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).astype(np.float32)
+    bn = (g.uniform(0.5, 1.5, cout), g.standard_normal(cout) * 0.1, g.standard_normal(cout) * 0.1, g.uniform(0.5, 1.5, cout))
+    ys = []
+    for sw in ("1", "0", "1"):
+        monkeypatch.setenv("VK_WS_STRIDED", sw)
+        ys.append(G.conv2d(x, w, bn=bn, stride=stride, relu=relu, dt=L.VK_F16))
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+    wf, bf = G.fold_ref(w, bn, L.VK_F16)
+    ref = F.conv2d(x.half().float(), wf, None, stride) + bf.view(1, -1, 1, 1)
+    assert G.rel_err(ys[0], (F.relu(ref) if relu else ref).half().float()) <= 1e-3
+
+
 @pytest.mark.parametrize("M_hw,cin,cout,res,relu", [((13, 14, 14), 2048, 512, False, True), ((11, 14, 14), 1024, 512, False, True),
                                                     ((17, 14, 14), 1024, 256, True, True), ((2, 50, 84), 1024, 256, False, False),
                                                     ((1, 45, 47), 1152, 512, True, False)])

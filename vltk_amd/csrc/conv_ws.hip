@@ -47,6 +47,7 @@ struct WsK {
     unsigned long *stamps;   // DBG & 32 builds only: 8 cycle sums per wave
     double *pool;            // POOL builds: per-image column sums [M / HW][Cout] (exact in fp64), y is not written
     int HW;                  // rows per image (>= 64: a 64-row tile touches at most two images)
+    int H, W, Wo, HoWo, stride;   // STRIDED builds: input geometry of a strided 1x1 conv (x rows are input pixels, M counts output pixels)
 };
 
 #define VKW_GLDS16(gptr, lptr)                                                                         \
@@ -80,7 +81,9 @@ constexpr int WS_BM = 64;                    // rows per tile
 // KC = 2 (K = 64: res2's conv3): ring stages of 64 channels (128-byte rows), one stage per tile.
 // DUAL (KC = 4): the 128-channel stage is [64 channels of x | 64 channels of x2] -- res2's first conv3 and its projection shortcut as
 // one GEMM (`out += shortcut`, frcnn.py:970-977; the weights hold the concatenated rows); a DMA lane picks its source by chunk.
-template <int KC, int NW, int DBG = 0, bool POOL = false, bool DUAL = false>
+// STRIDED: 1x1 conv with a stride (the stride-2 projection shortcuts and first conv1s of res3 / res4): the DMA lane turns its output
+// row into (image, ho, wo) and reads input pixel (ho * stride, wo * stride); everything behind the ring is unchanged.
+template <int KC, int NW, int DBG = 0, bool POOL = false, bool DUAL = false, bool STRIDED = false>
 __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!DUAL || KC == 4, "two sources: 64 + 64 channels");
@@ -144,7 +147,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
         for (int q = qlo; q < qhi; ++q) {
             const int row = (wave * PPW + q) * (64 / LPR) + drow;
             const int m = min(m0 + row, p.M - 1);                             // rows past M are computed and dropped
-            if constexpr (DUAL) {
+            if constexpr (STRIDED) {
+                const int n_ = m / p.HoWo, r_ = m - n_ * p.HoWo;
+                const int ho = r_ / p.Wo, wo = r_ - ho * p.Wo;
+                const long src = ((long)n_ * p.H + ho * p.stride) * p.W + wo * p.stride;
+                VKW_GLDS16(p.x + src * p.kbytes + st * PITCH + ((dslot ^ (row & (LPR - 1))) << 4), dst + q * 1024);
+            } else if constexpr (DUAL) {
                 const int c = dslot ^ (row & (LPR - 1));                          // chunk 0-7: x, 8-15: x2 (one stage per tile)
                 VKW_GLDS16((c < 8 ? p.x : p.x2) + (long)m * 128 + ((c & 7) << 4), dst + q * 1024);
             } else {
@@ -428,7 +436,11 @@ bool conv_ws_eligible(const ConvArgs &a) {
     if (v && v[0] == '0') return false;
     if (a.pool_part) return conv_ws_pool_ok(a);
     if (a.stem || a.groups > 1 || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return false;
-    if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
+    if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride < 1) return false;
+    if (a.stride != 1) {                                                  // strided: K = 256 / 512, one source, no residual rows to map
+        const char *sv = getenv("VK_WS_STRIDED");                         // "0": strided 1x1 convs stay on the two-per-CU kernel (A/B switch)
+        if ((sv && sv[0] == '0') || a.x2 || a.res || (a.Cin != 256 && a.Cin != 512)) return false;
+    }
     if (a.x2 && (a.Cin != 64 || a.Cin2 != 64)) return false;             // two sources: 64 + 64 channels only
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256 && a.Cin != 512)) return false;
     const int nt = a.Cout / 256;
@@ -437,15 +449,15 @@ bool conv_ws_eligible(const ConvArgs &a) {
     return M >= 8 * 128 && M < (1L << 31) - 128;      // (a.Cin % 128 == 0: whole 128-channel ring stages)
 }
 
-template <int KC, int NW = 8, int DBG = 0, bool POOL = false, bool DUAL = false>
+template <int KC, int NW = 8, int DBG = 0, bool POOL = false, bool DUAL = false, bool STRIDED = false>
 static int launch_ws(const WsK &k, hipStream_t stream) {
     constexpr int smem = 6 * WS_BM * 256 + 4 * WS_BM * 128 + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG, POOL, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_kernel<KC, NW, DBG, POOL, DUAL, STRIDED>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG, POOL, DUAL>), dim3(256), dim3(NW * 64), smem, stream, k);
+    hipLaunchKernelGGL((conv_ws_kernel<KC, NW, DBG, POOL, DUAL, STRIDED>), dim3(256), dim3(NW * 64), smem, stream, k);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }
@@ -468,6 +480,11 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     k.stamps = nullptr;
     k.pool = (double *)a.pool_part;
     k.HW = a.Ho * a.Wo;
+    k.H = a.H;
+    k.W = a.W;
+    k.Wo = a.Wo;
+    k.HoWo = a.Ho * a.Wo;
+    k.stride = a.stride;
 
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -513,7 +530,9 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         const int dbg = d ? atoi(d) : 0;
 #define VKW_DBG_CASE(NW_, D_) \
     case D_: st = launch_ws<16, NW_, D_>(k, stream); break;
-        if (a.x2)
+        if (a.stride != 1)
+            st = a.Cin == 256 ? launch_ws<8, 8, 0, false, false, true>(k, stream) : launch_ws<16, 8, 0, false, false, true>(k, stream);
+        else if (a.x2)
             st = launch_ws<4, 8, 0, false, true>(k, stream);
         else if (a.Cin == 64)
             st = nw == 8 ? launch_ws<2, 8>(k, stream) : launch_ws<2, 4>(k, stream);
