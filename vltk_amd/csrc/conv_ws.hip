@@ -1,6 +1,8 @@
 // 1x1 convolution with K <= 512 input channels as a WEIGHT-STATIONARY GEMM: the conv3 layers of the bottlenecks
 // (`out = conv3(out) + shortcut`, reference vltk/modeling/frcnn.py:970-979: 512 -> 2048 in the Res5 head, 256 -> 1024 in
-// res4, 128 -> 512 in res3).
+// res4, 128 -> 512 in res3, 64 -> 256 in res2), res2's first conv3 with its projection shortcut as one GEMM (64 + 64 channels
+// from two tensors), the strided 1x1 convs of res3 / res4 (K = 256 / 512), and the last Res5 conv3 with the spatial mean fused
+// (see the template's comments for the three variants).
 //
 // Why: these layers are bound by what a CU can move through its vector-memory path (~21 B/clk measured), not by
 // the matrix cores and not by HBM.  A 128 x 256 tile of the two-per-CU kernel (conv_mfma_duo.hip) moves, per output element
