@@ -81,7 +81,8 @@ def stage_fractions(st, B, R, arch):
     return out
 
 
-PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_MFMA_FILES = ("r03_pmc_mfma.json",)
 
 
 def pmc_traffic(batch, proposals, kernel):
@@ -97,8 +98,134 @@ def pmc_traffic(batch, proposals, kernel):
         for e in (d.get("kernels") or [d]):
             if e.get("batch", d.get("batch")) == batch and e.get("proposals", d.get("proposals")) == proposals \
                     and e.get("kernel") == kernel:
-                return e["hbm_bytes_per_launch"], "profiles/" + fn
+                return e["hbm_bytes_per_launch"], "profiles/" + fn, e.get("alg_bytes_per_launch"), e.get("kernel_symbol_filter")
+    return None, None, None, None
+
+
+def pmc_mfma(kernel):
+    """MFMA-pipe busy fraction and effective clock of `kernel` from the committed SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE
+    pass (tools/pmc_mfma_summary.py; not measurable from inside the process): ({...}, source) or (None, None)."""
+    for fn in PMC_MFMA_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except Exception:
+            continue
+        rows = [r for r in d.get("kernels", []) if kernel in r.get("kernel", "")]
+        if rows:
+            r = max(rows, key=lambda r: r["gpu_ms"])
+            return {"kernel": r["kernel"], "mfma_busy_frac": r["mfma_busy_frac"], "effective_clock_ghz": r["effective_clock_ghz"],
+                    "dispatches": r["dispatches"]}, "profiles/" + fn
     return None, None
+
+
+def _rel(a, b):
+    import numpy as np
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)) if a.size else 0.0
+
+
+def _match_rows(boxes_a, boxes_b, tol):
+    """Rows of a and b (two [n,4] arrays) whose boxes coincide within `tol` pixels: [(i, j)]."""
+    import numpy as np
+    pairs = []
+    if len(boxes_a) == 0 or len(boxes_b) == 0:
+        return pairs
+    for i in range(len(boxes_a)):
+        d = np.abs(boxes_b - boxes_a[i]).max(axis=1)
+        j = int(d.argmin())
+        if d[j] <= tol:
+            pairs.append((i, j))
+    return pairs
+
+
+def parity_record(device):
+    """Deviation of the TIMED mode (fp16 storage, fp32 accumulate) from fp32, measured in this run, outside the timed region.
+
+    (1) `reference_golden`: the committed vectors the reference's OWN module produced (tests/golden/e2e_r101_small.npz,
+        tools/gen_golden.py): 2 images 160x224, ResNet-101-C4, R = 30, D = 12.
+    (2) `full_size`: one 800x1333 image at the benched configuration (R = 300, D = 100) against this library's strict fp32
+        mode on the same weights (the strict mode itself is held to the reference golden and, at full size, to the oracle
+        at <= 1e-3 by tests/test_gpu_e2e.py / tests/test_gpu_fullsize.py; measured ~1e-5).
+    Metric everywhere: max |a - b| / max |b| (tests/gpu_util.py rel_err).  Logits are compared on the proposals both runs
+    share (boxes within 0.05 px: the same RoIPool bins).  north_star asks 1e-3 on RoI features and logits: `meets_1e-3`
+    says which of them the timed mode meets.  CPU attribution: with every activation kept in fp32 the
+    full-size logits are still 1.07e-3 off (fp16 weights alone), with fp32 weights 1.22e-3 (fp16 storage alone): no single
+    stage carries the error, so no cheap stage-local fix exists; the strict mode is the 1e-3 path."""
+    import numpy as np
+    import torch
+    from vltk_amd import FRCNN, make_state_dict, synthetic_images, vg_c4_config
+    rec = {"metric": "max|a-b| / max|b|", "tolerance_north_star": 1e-3}
+    # ---- (1) the reference's golden vectors ----
+    gpath = os.path.join(ROOT, "tests", "golden", "e2e_r101_small.npz")
+    if os.path.exists(gpath):
+        g = np.load(gpath)
+        n, h, w = g["nhw"].tolist()
+        cfg = vg_c4_config(depth=int(g["depth"]), post_nms_topk=int(g["post_topk"]), detections=int(g["det"]), device=device)
+        sd = make_state_dict(cfg, seed=int(g["weights_seed"]))
+        x = synthetic_images(n, h, w, seed=int(g["images_seed"]))
+        shapes = g["shapes"].tolist()
+        for i, (hh, ww) in enumerate(shapes):
+            x[i, :, hh:, :] = 0
+            x[i, :, :, ww:] = 0
+        m = FRCNN(cfg, precision="fp16", device=device).load_state_dict(sd).eval()
+        out = m(torch.from_numpy(x), torch.tensor(shapes))
+        R = int(g["post_topk"])
+        pb, pc = m.get_stage("proposal_boxes").cpu().numpy(), m.get_stage("proposal_counts").cpu().numpy()
+        ol, al = m.get_stage("obj_logits").cpu().numpy(), m.get_stage("attr_logits").cpu().numpy()
+        C1, A1 = g["obj_logits"].shape[1], g["attr_logits"].shape[1]
+        ra, rb, off = [], [], 0
+        for i in range(n):
+            gb = g[f"proposal_boxes_{i}"]
+            for a_, b_ in _match_rows(pb[i, :int(pc[i])], gb, 0.05):
+                ra.append(i * R + a_)
+                rb.append(off + b_)
+            off += len(gb)
+        same_det = all(out["obj_ids"][i].cpu().numpy().tolist() == g[f"obj_ids_{i}"].tolist() for i in range(n))
+        la, lb = ol[ra][:, :C1], g["obj_logits"][rb]
+        same_cls = la.argmax(-1) == lb.argmax(-1)
+        e = {"roi_features": max(_rel(out["roi_features"][i].cpu().numpy(), g[f"roi_features_{i}"]) for i in range(n)) if same_det else None,
+             "boxes": max(_rel(out["boxes"][i].cpu().numpy(), g[f"boxes_{i}"]) for i in range(n)) if same_det else None,
+             "obj_probs": max(_rel(out["obj_probs"][i].cpu().numpy(), g[f"obj_probs_{i}"]) for i in range(n)) if same_det else None,
+             "obj_logits": _rel(la, lb), "attr_logits": _rel(al[ra][:, :A1][same_cls], g["attr_logits"][rb][same_cls]),
+             "res4": _rel(m.get_stage("res4").float().permute(0, 3, 1, 2).cpu().numpy(), g["res4"])}
+        rec["reference_golden"] = {"fixture": "tests/golden/e2e_r101_small.npz (reference module's own output, fp32)",
+                                   "detections_identical": bool(same_det), "proposals_shared": f"{len(ra)} of {off}",
+                                   **{k: (round(v, 6) if v is not None else None) for k, v in e.items()}}
+        del m
+    # ---- (2) one full-size image at the benched configuration against the strict fp32 mode ----
+    cfg = vg_c4_config(post_nms_topk=300, detections=100, device=device)
+    sd = make_state_dict(cfg, seed=1234)
+    x = torch.from_numpy(synthetic_images(1, 800, 1333, seed=0xF2C))
+    shapes = torch.tensor([[800, 1333]])
+    res = {}
+    for prec in ("fp32", "fp16"):
+        m = FRCNN(cfg, precision=prec, device=device).load_state_dict(sd).eval()
+        out = m(x, shapes)
+        c = int(m.get_stage("proposal_counts").cpu()[0])
+        res[prec] = {"out": {k: (v[0].cpu().numpy() if isinstance(v, list) else v) for k, v in out.items()},
+                     "pb": m.get_stage("proposal_boxes").cpu().numpy()[0, :c], "feat": m.get_stage("feature_pooled").cpu().numpy()[:c],
+                     "ol": m.get_stage("obj_logits").cpu().numpy()[:c, :1601], "al": m.get_stage("attr_logits").cpu().numpy()[:c, :401],
+                     "res4": m.get_stage("res4").float().cpu().numpy()}
+        del m
+    a, b = res["fp16"], res["fp32"]
+    pairs = _match_rows(a["pb"], b["pb"], 0.05)
+    ia, ib = [p_[0] for p_ in pairs], [p_[1] for p_ in pairs]
+    same_cls = a["ol"][ia].argmax(-1) == b["ol"][ib].argmax(-1)
+    det = _match_rows(a["out"]["boxes"], b["out"]["boxes"], 1.0)
+    det_same = [(i, j) for i, j in det if int(a["out"]["obj_ids"][i]) == int(b["out"]["obj_ids"][j])]
+    fi, fj = [p_[0] for p_ in det_same], [p_[1] for p_ in det_same]
+    full = {"against": "this library's strict fp32 mode, same weights and image (pinned to the reference / the oracle by the -m gpu tests)",
+            "res4": round(_rel(a["res4"], b["res4"]), 6), "proposals_shared": f"{len(pairs)} of {len(b['pb'])} (boxes within 0.05 px)",
+            "feature_pooled": round(_rel(a["feat"][ia], b["feat"][ib]), 6), "obj_logits": round(_rel(a["ol"][ia], b["ol"][ib]), 6),
+            "attr_logits": round(_rel(a["al"][ia][same_cls], b["al"][ib][same_cls]), 6),
+            "detections_matched": f"{len(det_same)} of {len(a['out']['boxes'])} (box within 1 px and same class; fp32 run: {len(b['out']['boxes'])})",
+            "roi_features_of_matched_detections": round(_rel(a["out"]["roi_features"][fi], b["out"]["roi_features"][fj]), 6) if fi else None,
+            "boxes_of_matched_detections_px": round(float(np.abs(a["out"]["boxes"][fi] - b["out"]["boxes"][fj]).max()), 4) if fi else None}
+    rec["full_size"] = full
+    g_ = rec.get("reference_golden", {})
+    rec["meets_1e-3"] = {"roi_features": bool((g_.get("roi_features") or 1) <= 1e-3 and full["feature_pooled"] <= 1e-3),
+                         "logits": bool(max(g_.get("obj_logits", 1), g_.get("attr_logits", 1), full["obj_logits"], full["attr_logits"]) <= 1e-3)}
+    return rec
 
 
 def cpu_baseline(cfg, sd, R, det, seed, n_images=4, repeats=3):
@@ -195,6 +322,7 @@ def main():
     ap.add_argument("--detections", type=int, default=100)
     ap.add_argument("--head-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-fp32 parity record (a few seconds, outside the timed region)")
     ap.add_argument("--arch", default="r101", choices=["r101", "x152", "r101-fpn"],
                     help="r101 = the BASELINE workload (configs[1], C4: the model the reference has); x152 = ResNeXt-152 32x8d C4 "
                          "(SURVEY.md 8d config c4, extra); r101-fpn = the FPN detector (build extension, UNPINNED vs the reference, extra)")
@@ -366,7 +494,8 @@ def main():
         dom = kt[dom_key]
         dom_name, dom_desc = KERNEL_NAMES[dom_key]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(B, a.proposals, dom_name)
+        traffic, traffic_src, traffic_alg, traffic_sym = pmc_traffic(B, a.proposals, dom_name)
+        mfma_busy, mfma_src = pmc_mfma(dom_name)
         all_ms = sum(v["ms"] for v in kt.values())
         all_fl = sum(v["flops"] for v in kt.values())
         line = {
@@ -383,6 +512,10 @@ def main():
                        "global_batch": world * B, "parallelism": f"image-sharded x{world}, all-gather of output blocks"},
             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         # `traffic` covers the launches the PMC filter selects (e.g. the Res5 conv2 launches of the panel kernel);
+                         # traffic_alg_bytes are the algorithmic bytes of exactly those, alg_bytes_per_launch the average over ALL launches
+                         "traffic_launches": traffic_sym, "traffic_alg_bytes": traffic_alg,
+                         "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
                          "alg_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
@@ -403,6 +536,11 @@ def main():
                          "note": "per-kernel and per-stage figures are from the breakdown pass (timers on), value / ms_per_step "
                                  "from the headline pass (timers off)"},
         }
+        if a.arch == "r101" and not a.no_parity:
+            try:
+                line["parity"] = parity_record(f"cuda:{local_rank}")
+            except Exception as e:          # never lose the bench line to the side record
+                line["parity"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, a.proposals, a.detections, seed=0xF2C)
         sys.stdout.flush()

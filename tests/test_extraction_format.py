@@ -82,3 +82,32 @@ def test_matches_reference_fixture(tmp_path):
     assert a == b
     assert type(json.loads(ref.schema.metadata[b"img_to_row_map"])) is type(json.loads(ours.schema.metadata[b"img_to_row_map"]))
     assert ref.schema.metadata[b"model_config"] == ours.schema.metadata[b"model_config"] == b"None"
+
+
+def test_error_inside_writer_block_leaves_nothing_behind(tmp_path):
+    """An exception inside the `with` block closes the sink and removes `<split>.arrow.tmp`."""
+    path = str(tmp_path / "train.arrow")
+    with pytest.raises(RuntimeError):
+        with ExtractionWriter(path, 4, 8) as w:
+            w.write_batch(["a"], np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32), np.zeros((1, 4, 4), np.float32),
+                          np.zeros((1, 4, 8), np.float32))
+            raise RuntimeError("forward failed")
+    assert os.listdir(tmp_path) == []
+
+
+def test_extract_restores_the_callers_detection_limits(tmp_path, monkeypatch):
+    """`extract()` sets roi_outputs.{max,min}_detections to the schema's width for the call only, also when it fails."""
+    from types import SimpleNamespace
+    from vltk_amd.adapters import FRCNN as Adapter
+    (tmp_path / "train").mkdir()
+    model = SimpleNamespace(roi_outputs=SimpleNamespace(max_detections=36, min_detections=36), visual_dim=2048)
+    seen = {}
+
+    def boom(cls, model, *a, **k):
+        seen["limits"] = (model.roi_outputs.max_detections, model.roi_outputs.min_detections)
+        raise RuntimeError("split failed")
+    monkeypatch.setattr(Adapter, "_extract_splits", classmethod(boom))
+    with pytest.raises(RuntimeError):
+        Adapter.extract(str(tmp_path), model=(model, {}), max_detections=10)
+    assert seen["limits"] == (10, 10)
+    assert (model.roi_outputs.max_detections, model.roi_outputs.min_detections) == (36, 36)

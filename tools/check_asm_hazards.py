@@ -10,7 +10,8 @@ rare wrong 16-row blocks.  The kernels are therefore written so that every loop 
 the LDS read queue (reads return in order; `lgkmcnt(N)` retires all but the N newest) and the queue of global loads into
 registers (`vmcnt`), and reports every instruction that touches a register with a pending read.
 
-usage: python tools/check_asm_hazards.py [file.hip ...]      exit code 1 if any hazard is found
+usage: python tools/check_asm_hazards.py [--hipcc PATH] [--quiet] [file.hip ...]      exit code 1 if any hazard is found
+(vltk_amd/csrc/Makefile runs it after the link and fails the build on a hit; validated with hipcc 7.2.26015 / clang 22.0.0git roc-7.2.0)
 """
 import os
 import re
@@ -172,22 +173,34 @@ def scan_file(path, hipcc="hipcc", scan=None):
 
 
 def main():
-    files = sys.argv[1:] or [os.path.join(CSRC, f) for f in DEFAULT]
+    argv = sys.argv[1:]
+    hipcc, quiet = "hipcc", False
+    if "--hipcc" in argv:
+        i = argv.index("--hipcc")
+        hipcc = argv[i + 1]
+        del argv[i:i + 2]
+    if "--quiet" in argv:
+        quiet = True
+        argv.remove("--quiet")
+    files = argv or [os.path.join(CSRC, f) for f in DEFAULT]
     bad = 0
     for f in files:
-        for name, found in scan_file(f).items():
-            print(f"{os.path.basename(f)}  {name}: {len(found)} hazard(s)")
+        for name, found in scan_file(f, hipcc=hipcc).items():
+            if found or not quiet:
+                print(f"{os.path.basename(f)}  {name}: {len(found)} hazard(s)")
             ablation = "conv_gemm4_kernel" in name and "ILb0ELi0ELi" not in name   # stamp / timing-only DBG builds (dummy reads): not product code
             for i, t, li in found[:0 if ablation else 6]:
                 print(f"    line +{i}: {t}    <- ds_read at +{li} still pending")
             bad += 0 if ablation else len(found)
-        for name, found in scan_file(f, scan=scan_asm_mfma_region).items():
+        for name, found in scan_file(f, hipcc=hipcc, scan=scan_asm_mfma_region).items():
             if found:
                 print(f"{os.path.basename(f)}  {name}: {len(found)} compiler VALU / accumulator instruction(s) between asm MFMAs")
                 for i, t in found[:6]:
                     print(f"    +{i}: {t}")
                 if "ILb0ELi0ELi" in name:                   # stamp and ablation builds are not product code
                     bad += len(found)
+    if quiet:
+        print(f"check_asm_hazards: {len(files)} file(s), {bad} hazard(s) in product builds")
     return 1 if bad else 0
 
 

@@ -4,6 +4,9 @@
 Runs one stamped launch (VK_DUO_STAMPS) of a tools/conv_bench.py shape after warm-up launches and prints, per
 phase, the median duration, plus how the two workgroups that share a CU overlap.
 usage: python tools/duo_stamps.py head_conv3 [out_file]
+
+Needs the tools build of the library (make -C vltk_amd/csrc clean && make -C vltk_amd/csrc -j8 ABLATION=1): the shipped
+build has no stamp / ablation instantiations and ignores the VK_*_STAMPS / VK_*_DBG variables.
 """
 import collections
 import os

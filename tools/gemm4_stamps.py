@@ -3,7 +3,10 @@
 
 Two seconds of back-to-back launches on random data, then one stamped launch (VK_GEMM4_STAMPS, conv_gemm4.hip STAMP build):
 clock = s_memtime ticks / s_memrealtime ticks x 100 MHz around the K loop, median over workgroups; a stage is 64 MFMAs per wave
-= 1024 matrix-pipe cycles.  usage: python tools/gemm4_stamps.py [shape]"""
+= 1024 matrix-pipe cycles.  usage: python tools/gemm4_stamps.py [shape]
+Needs the tools build of the library (make -C vltk_amd/csrc clean && make -C vltk_amd/csrc -j8 ABLATION=1): the shipped
+build has no stamp / ablation instantiations and ignores the VK_*_STAMPS / VK_*_DBG variables.
+"""
 import os
 import sys
 import time

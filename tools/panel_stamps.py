@@ -3,7 +3,10 @@
 
 Two seconds of back-to-back launches on random data, then one stamped launch (VK_PANEL_STAMPS, conv3x3_panel.hip DBG 4).
 A step (one tap of one 32-channel stage) is 32 MFMAs per wave on two waves per SIMD = 1024 matrix-pipe cycles.
-usage: python tools/panel_stamps.py [shape]"""
+usage: python tools/panel_stamps.py [shape]
+Needs the tools build of the library (make -C vltk_amd/csrc clean && make -C vltk_amd/csrc -j8 ABLATION=1): the shipped
+build has no stamp / ablation instantiations and ignores the VK_*_STAMPS / VK_*_DBG variables.
+"""
 import os
 import sys
 import time

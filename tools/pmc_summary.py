@@ -38,6 +38,8 @@ if "--json" in sys.argv:
                          "(MI355X_MICROARCH.md, HBM section)",
            "hbm_bytes_per_launch": round((2 * fetch + write) * 1024 / launches),
            "min_workgroups": int(opt["--min-workgroups"]),
+           # algorithmic bytes (input + output (+ residual) + weights once) of exactly the launches the filter selects, if given
+           "alg_bytes_per_launch": int(opt["--alg-bytes"]) if "--alg-bytes" in opt else None,
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"}
     json.dump(out, open(opt["--json"], "w"), indent=1)
     print("wrote", opt["--json"], out["hbm_bytes_per_launch"])

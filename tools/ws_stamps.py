@@ -5,6 +5,9 @@ One stamped launch (VK_WS_STAMPS, conv_ws.hip DBG & 32) of the Res5 conv3 shape 
 per-wave cycle sums: waiting for DMA, at the stage barrier, stage body (fragment reads + MFMAs + DMA issue), waiting for the
 residual rows, epilogue.
 usage: VK_WS_WAVES=4|8 python tools/ws_stamps.py [shape]
+
+Needs the tools build of the library (make -C vltk_amd/csrc clean && make -C vltk_amd/csrc -j8 ABLATION=1): the shipped
+build has no stamp / ablation instantiations and ignores the VK_*_STAMPS / VK_*_DBG variables.
 """
 import os
 import sys

@@ -312,7 +312,12 @@ class FRCNN:
         `schema`'s (max_detections, visual_dim), `setup`'s (path, synthetic, precision, seed, model_config), plus
         `model=(model, model_config)` to reuse a built model and `batch_size` (images per forward, default 32).
         With torch.distributed initialised the images of every split shard across the ranks (parallel.py); the dict is
-        returned on rank 0 (empty elsewhere)."""
+        returned on rank 0 (empty elsewhere).  `model.roi_outputs.{max,min}_detections` are set to the schema's width for
+        the call and restored afterwards.  The reference-processor mode (`processor="reference"` / a `processor_config`)
+        keeps an upstream quirk on purpose: `entry["size"]` is PIL's (W, H) and goes to the model as `image_shapes`, whose
+        rows mean (h, w) (adapters/frcnn.py:50-52 with processing/image.py:139-141; upstream calls that processor
+        "incorrect" itself, adapters/frcnn.py:12) -- boxes are therefore clipped to the transposed extent there.  The
+        default GPU path follows the legacy (correct) contract."""
         from .extraction import ExtractionWriter, load_extraction
         dataset_name = dataset if dataset is not None else kwargs.pop("dataset_name", None)
         kwargs.pop("dataset_name", None)
@@ -329,9 +334,22 @@ class FRCNN:
         sch = _collect_args(cls.schema, kwargs)
         D = int(sch.get("max_detections", model.roi_outputs.max_detections))
         F = int(sch.get("visual_dim", getattr(model, "visual_dim", 2048)))
-        if D != int(model.roi_outputs.max_detections):                      # rows are padded to the schema's width
-            model.roi_outputs.max_detections = D
-            model.roi_outputs.min_detections = min(int(model.roi_outputs.min_detections), D)
+        # the caller's model keeps its limits: they are set for this call and restored on every way out
+        saved_limits = (model.roi_outputs.max_detections, model.roi_outputs.min_detections)
+        try:
+            if D != int(model.roi_outputs.max_detections):                  # rows are padded to the schema's width
+                model.roi_outputs.max_detections = D
+                model.roi_outputs.min_detections = min(int(model.roi_outputs.min_detections), D)
+            splitdict = cls._extract_splits(model, model_config, searchdirs, valid_splits, savedir, dataset_name, subset_ids,
+                                            processor, processor_config, batch_size, D, F, kwargs)
+        finally:
+            model.roi_outputs.max_detections, model.roi_outputs.min_detections = saved_limits
+        return splitdict
+
+    @classmethod
+    def _extract_splits(cls, model, model_config, searchdirs, valid_splits, savedir, dataset_name, subset_ids, processor,
+                        processor_config, batch_size, D, F, kwargs):
+        from .extraction import ExtractionWriter, load_extraction
         # files -> per split (id, path), in the reference's terms: split = parent directory, id = stem up to the first dot
         print(f"extracting from {searchdirs}")
         per_split = {s: [] for s in valid_splits}
@@ -365,6 +383,12 @@ class FRCNN:
                      "format": "BGR", "pad_value": float(model_config.PAD_VALUE), "device": "gpu"}
         import torch.distributed as dist
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+        if gpu_path and world > 1:      # checked for EVERY split before the first one is written
+            short = {sp: len(it) for sp, it in per_split.items() if it and len(it) < world}
+            if short:
+                raise ValueError(f"splits with fewer images than ranks ({world}): {short}; nothing was written")
+        if not gpu_path and world > 1:
+            raise NotImplementedError("the per-image reference loop is single-process; use the default GPU path")
         splitdict = {}
         for split, items in per_split.items():
             if not items:
@@ -374,8 +398,6 @@ class FRCNN:
                 cls._extract_split_gpu(model, model_config, items, savefile, dataset_name, pargs, cfgd, batch_size, F,
                                        rank, world)
             else:
-                if world > 1:
-                    raise NotImplementedError("the per-image reference loop is single-process; use the default GPU path")
                 fkw = _collect_args(cls.forward, kwargs)
                 fkw.pop("model", None), fkw.pop("entry", None)
                 with ExtractionWriter(savefile, D, F, dataset=dataset_name, processor_args=pargs, model_config=cfgd) as w:

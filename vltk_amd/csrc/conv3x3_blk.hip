@@ -237,6 +237,7 @@ static int blk_variant(const ConvArgs &a) {
     if (a.stem || a.x2 || a.pool_part || a.res || a.dt != VK_F16 || a.out_dt != VK_F16 || a.relu > 1) return 0;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != a.dil || a.Cin != a.Cout || a.ldy != a.Cout) return 0;
     if (a.Cin % 64 != 0 || a.H != a.Ho || a.W != a.Wo) return 0;
+    if ((long)(a.H + 8) * a.W * a.Cin * 2 >= (1L << 31)) return 0;      // 32-bit in-image offsets: larger images stay on conv_mfma.hip
     int cb;
     if (a.groups > 1) {
         if (a.Cin % a.groups != 0) return 0;
@@ -257,16 +258,22 @@ bool conv3x3_blk_eligible(const ConvArgs &a) { return blk_variant(a) != 0; }
 template <int CB, int TH, int TW, int VW, int DIL>
 static int launch_blk(const ConvArgs &a, hipStream_t stream) {
     constexpr int smem = 2 * ((((TH + 2 * DIL) * (TW + 2 * DIL) + 7) / 8 + 7) / 8) * 8 * 1024 + 256;
-    static char *zero_page = nullptr;
-    if (!zero_page) {
-        VK_CHECK_HIP(hipMalloc((void **)&zero_page, 256));
-        VK_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    // per device: the zero page lives in the memory of the device that reads it, and the LDS attribute is set on each
+    // device's copy of the code object (a process may hold handles on several GPUs: vk_create takes a device index)
+    int dev = 0;
+    VK_CHECK_HIP(hipGetDevice(&dev));
+    VK_REQUIRE(dev >= 0 && dev < VK_MAX_DEVICES, VK_EINVAL, "conv3x3_blk: device index %d", dev);
+    static char *zero_pages[VK_MAX_DEVICES] = {};
+    if (!zero_pages[dev]) {
+        VK_CHECK_HIP(hipMalloc((void **)&zero_pages[dev], 256));
+        VK_CHECK_HIP(hipMemset(zero_pages[dev], 0, 256));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    char *zero_page = zero_pages[dev];
+    static bool attr_set[VK_MAX_DEVICES] = {};
+    if (!attr_set[dev]) {
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_blk_kernel<CB, TH, TW, VW, DIL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     BlkK k;
     k.x = (const char *)a.x;
@@ -285,7 +292,6 @@ static int launch_blk(const ConvArgs &a, hipStream_t stream) {
     VK_REQUIRE(nt > 0 && nt < (1L << 31), VK_EINVAL, "conv3x3_blk: %ld tiles", nt);
     k.ntiles = (int)nt;
     k.zero = zero_page;
-    VK_REQUIRE((long)(a.H + 8) * a.W * a.Cin * 2 < (1L << 31), VK_EINVAL, "conv3x3_blk: image too large for 32-bit in-image offsets");
     const int slabs = a.Cin / 64;
     // one workgroup per CU over all slabs; a workgroup keeps its slab's weights in registers across its tiles
     int gx = 256 / slabs;

@@ -569,7 +569,9 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
     const dim3 grid(k.m_tiles * k.n_tiles), block(512);
+#ifdef VK_ABLATION
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
+#endif
     const int smem = 2 * pp * 128 * 64 + P_NW * P_WSLOT;
     k.stamps = nullptr;
 #define VKP_LAUNCH(PP_, DBG_, TAG_, MI_)                                                                                                   \
@@ -582,6 +584,7 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
         }                                                                                                                                  \
         hipLaunchKernelGGL((conv3x3_panel_kernel<PP_, DBG_, TAG_, MI_>), grid, block, smem, stream, k);                                     \
     } while (0)
+#ifdef VK_ABLATION      // stamp / timing-only (dbg 1: WRONG results) / LDS-epilogue builds: tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_PANEL_STAMPS"); sf && pp == 3) {   // diagnostic: one stamped launch (halo-64 / 48 build), 4 words per workgroup appended to the file
         const size_t nb = (size_t)grid.x * 4 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
@@ -602,7 +605,9 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
         VKP_LAUNCH(3, 8, 0, 8);
     else if (mi == 8 && pp == 3 && dbg == 1)
         VKP_LAUNCH(3, 1, 0, 8);
-    else if (mi == 8 && pp == 3 && a.concurrent)
+    else
+#endif
+    if (mi == 8 && pp == 3 && a.concurrent)
         VKP_LAUNCH(3, 0, 1, 8);
     else if (mi == 8 && pp == 3)
         VKP_LAUNCH(3, 0, 0, 8);

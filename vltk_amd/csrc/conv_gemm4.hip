@@ -475,7 +475,9 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
+#ifdef VK_ABLATION
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
+#endif
         attr_set = true;
     }
     const int cin2 = a.x2 ? a.Cin2 : 0;
@@ -518,6 +520,7 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     }
     const int total_tiles = k.m_tiles * k.n_tiles;
     const int grid_wgs = total_tiles < n_cu ? total_tiles : n_cu;
+#ifdef VK_ABLATION      // stamp / timing-only builds (WRONG results for DBG != 0): tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_GEMM4_STAMPS")) {    // diagnostic: one stamped launch, 4 words per workgroup appended to the file
         const int nwg = grid_wgs;
         const size_t nb = (size_t)nwg * 8 * sizeof(unsigned long);
@@ -549,7 +552,9 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     } else if (getenv("VK_GEMM4_DBG") && atoi(getenv("VK_GEMM4_DBG")) == 128) {      // bisect: builtin MFMAs
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
         hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
-    } else if (a.concurrent) {
+    } else
+#endif
+    if (a.concurrent) {
         static bool attr1 = false;
         if (!attr1) {
             VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));

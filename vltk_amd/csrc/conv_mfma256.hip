@@ -522,6 +522,7 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
         }
         hipLaunchKernelGGL((conv_mfma256_kernel<0, true>), grid, block, R_SMEM, stream, k);
     } else
+#ifdef VK_ABLATION      // timing-only ablation builds (WRONG results): tools/ builds only (make ABLATION=1)
     switch (dbg) {
         case 1: hipLaunchKernelGGL(conv_mfma256_kernel<1>, grid, block, R_SMEM, stream, k); break;
         case 2: hipLaunchKernelGGL(conv_mfma256_kernel<2>, grid, block, R_SMEM, stream, k); break;
@@ -534,6 +535,12 @@ int launch_conv256(const ConvArgs &a, hipStream_t stream) {
         case 96: hipLaunchKernelGGL(conv_mfma256_kernel<96>, grid, block, R_SMEM, stream, k); break;
         default: hipLaunchKernelGGL(conv_mfma256_kernel<0>, grid, block, R_SMEM, stream, k);
     }
+#else
+    {
+        (void)dbg;
+        hipLaunchKernelGGL(conv_mfma256_kernel<0>, grid, block, R_SMEM, stream, k);
+    }
+#endif
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
         VK_CHECK_HIP(hipEventRecord(e1, stream));

@@ -634,6 +634,7 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
     const dim3 grid(k.m_tiles * k.n_tiles), block(256);
     k.pool_part = (int *)a.pool_part;
     k.stamps = nullptr;
+#ifdef VK_ABLATION      // stamp / timing-only builds: tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_DUO_STAMPS")) {      // diagnostic: one launch, phase stamps appended to the file
         const size_t nb = (size_t)grid.x * 12 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
@@ -658,6 +659,7 @@ int launch_conv_duo(const ConvArgs &a, hipStream_t stream) {
             fclose(f);
         }
     } else
+#endif
         if (a.dt == VK_BF16 && a.relu == 2)
             hipLaunchKernelGGL((conv_duo_kernel<__bf16, false, 3, 0, true>), grid, block, d_smem(3), stream, k);
         else if (a.dt == VK_BF16)

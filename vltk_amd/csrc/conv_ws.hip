@@ -508,6 +508,7 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
     }
     const char *nwv = getenv("VK_WS_WAVES");             // "4" / "8": A/B switch, re-read per call
     const int nw = nwv ? atoi(nwv) : 8;
+#ifdef VK_ABLATION      // stamp build: tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_WS_STAMPS")) {       // diagnostic: one stamped launch (K = 512), cycle sums appended to the file
         if (a.Cin != 512) return VK_EINVAL;
         const size_t nb = (size_t)256 * 8 * 16 * sizeof(unsigned long);
@@ -527,11 +528,18 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
             }
             fclose(f);
         }
-    } else {
+    } else
+#endif
+    {
+#ifdef VK_ABLATION
         const char *d = getenv("VK_WS_DBG");
         const int dbg = d ? atoi(d) : 0;
 #define VKW_DBG_CASE(NW_, D_) \
     case D_: st = launch_ws<16, NW_, D_>(k, stream); break;
+#else      // the shipped library has no timing-only (WRONG-result) builds and ignores VK_WS_DBG / VK_WS_STAMPS
+        const int dbg = 0;
+#define VKW_DBG_CASE(NW_, D_)
+#endif
         if (a.stride != 1)
             st = a.Cin == 256 ? launch_ws<8, 8, 0, false, false, true>(k, stream) : launch_ws<16, 8, 0, false, false, true>(k, stream);
         else if (a.x2)

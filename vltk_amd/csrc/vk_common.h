@@ -48,6 +48,8 @@ static inline size_t dtype_size(vk_dtype dt) {
     return 0;
 }
 
+constexpr int VK_MAX_DEVICES = 64;      // per-device statics of the launchers (zero pages, function attributes)
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -138,9 +138,21 @@ class ExtractionWriter:
     def __enter__(self):
         return self
 
+    def abort(self):
+        """Drop what was written: close the sink, remove `<savefile>.tmp` (an error inside the `with` block must not leave either behind)."""
+        for obj in (self._writer, self._sink):
+            try:
+                obj.close()
+            except Exception:
+                pass
+        if os.path.exists(self._tmp):
+            os.remove(self._tmp)
+
     def __exit__(self, *exc):
         if exc[0] is None:
             self.close()
+        else:
+            self.abort()
 
 
 def load_extraction(path):
