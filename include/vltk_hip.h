@@ -179,9 +179,10 @@ int vk_get_stage_timing(vk_handle *h, float *ms6);
  * bucket 9: conv_mfma256_kernel<0, true> (the ring kernel's two-input build: conv3 + projection shortcut as one GEMM; its own
  *           symbol in a rocprofv3 trace)
  * bucket 10: conv_gemm4_kernel (1x1 with K >= 1024, one or two inputs: 256x256 tile, four waves of 128x128)
- * launches[11], ms[11], flops[11] (algorithmic 2*M*Cout*K of the launches), bytes[11] (algorithmic HBM bytes:
+ * bucket 11: bneck64_kernel (a whole res2 BottleneckBlock as one kernel: conv1 -> 3x3 -> conv3 + shortcut, 64 bottleneck channels)
+ * launches[12], ms[12], flops[12] (algorithmic 2*M*Cout*K of the launches), bytes[12] (algorithmic HBM bytes:
  * input + output (+ residual) + weights, each once). */
-#define VK_NUM_KERNEL_BUCKETS 11
+#define VK_NUM_KERNEL_BUCKETS 12
 int vk_enable_kernel_timing(vk_handle *h, int enable);
 int vk_get_kernel_timing(vk_handle *h, int64_t *launches, double *ms, double *flops, double *bytes, int reset);
 
@@ -216,6 +217,16 @@ int vk_conv2d(const void *x, int N, int H, int W, int cin,
 int vk_conv1x1_dual(const void *x1, int cin1, const void *x2, int cin2, long M,
                     const void *w_packed, const float *bias_packed, const void *residual,
                     void *y, int cout, int relu, void *stream);
+
+/* A whole stride-1 BottleneckBlock with 64 bottleneck channels and 256 outputs (res2) as ONE f16 kernel
+ * (BottleneckBlock.forward frcnn.py:963-979): y = relu(conv3(relu(conv2(relu(conv1 x)))) + shortcut(x)); the two 64-channel
+ * intermediates stay in LDS (rounded to f16 there, as the layer-by-layer path rounds them in HBM), x is read once.
+ * proj == 0: identity shortcut, cin == 256, w3 = conv3's packed rows [256][64].  proj != 0: projection shortcut of block 0,
+ * cin == 64, w3 = [conv3 row | shortcut row] per output channel and b3 = the two folded biases summed (vk_conv1x1_dual's
+ * layout).  w1 [>=64][cin], w2 [>=64][9*64] as vk_pack_conv_weight writes them.  x [N,H,W,cin], y [N,H,W,256]; N*H*W*512 < 2^31. */
+int vk_bottleneck64(const void *x, int N, int H, int W, int cin, int proj,
+                    const void *w1_packed, const float *b1_packed, const void *w2_packed, const float *b2_packed,
+                    const void *w3_packed, const float *b3_packed, void *y, void *stream);
 
 /* Last Res5 conv3 with the RoI's spatial mean folded into its epilogue (`res5(x).mean(dim=[2,3])`, frcnn.py:1401):
  * out_mean[n][c] = mean over the HW rows of image n of relu?(x . W^T + bias + residual), summed EXACTLY (integer

@@ -21,7 +21,7 @@ import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "vltk_amd", "csrc")
-DEFAULT = ["conv_mfma256.hip", "conv_mfma_duo.hip", "conv3x3_panel.hip", "conv_gemm4.hip"]
+DEFAULT = ["conv_mfma256.hip", "conv_mfma_duo.hip", "conv3x3_panel.hip", "conv_gemm4.hip", "bneck_fused.hip"]
 
 
 def _regs(tok):
@@ -78,7 +78,8 @@ def scan_function(lines):
             lab = ops[0]
             if lab in passed:                 # back-edge: nothing may be in flight (see the docstring)
                 for li, rs in list(pend) + list(vpend):
-                    found.append((i, t + "   [back-edge with a read in flight]", li))
+                    if rs:
+                        found.append((i, t + "   [back-edge with a read in flight]", li))
             else:
                 sp, sv = saved.get(lab, ([], []))
                 saved[lab] = (merge(sp, pend), merge(sv, vpend))
@@ -90,9 +91,12 @@ def scan_function(lines):
             if in_asm:
                 pend.append((i, set(_regs(ops[0]))))
             continue
-        if re.match(r"(global|buffer|flat)_load", op) and "_lds_" not in op and " lds" not in t:
-            if in_asm:
-                vpend.append((i, set(_regs(ops[0]))))
+        if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", op):
+            # every vector-memory instruction takes a place in the in-order vmcnt queue (LDS-DMA pieces, stores and the compiler's
+            # own loads too: they carry no registers to watch, but `vmcnt(N)` counts them); only HAND-ISSUED loads into registers
+            # are watched
+            is_load_to_regs = "_load" in op and "_lds_" not in op and " lds" not in t
+            vpend.append((i, set(_regs(ops[0])) if (in_asm and is_load_to_regs) else set()))
             continue
         if op.startswith("s_waitcnt"):
             m = re.search(r"lgkmcnt\((\d+)\)", t)
@@ -103,8 +107,8 @@ def scan_function(lines):
                 elif n < len(pend):
                     pend = pend[len(pend) - n:]
             m = re.search(r"vmcnt\((\d+)\)", t)
-            if m:          # other VMEM ops (LDS-DMA, stores) also count, so fewer of OUR loads may be pending than n: n == 0 is exact,
-                n = int(m.group(1))     # n > 0 conservatively keeps the newest n loads pending
+            if m:          # the queue holds every vector-memory instruction in issue order, so the newest n stay pending
+                n = int(m.group(1))
                 if n == 0:
                     vpend = []
                 elif n < len(vpend):

@@ -90,6 +90,7 @@ SIGNATURES = {
     "vk_packed_cout": (_I, [_I]),
     "vk_pack_conv_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "vk_conv1x1_dual": (_I, [_P, _I, _P, _I, C.c_long, _P, _P, _P, _P, _I, _I, _P]),
+    "vk_bottleneck64": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vk_conv1x1_meanpool_workspace_bytes": (_SZ, [_I, _I, _I]),
     "vk_conv1x1_meanpool": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _SZ, _P]),
     "vk_linear": (_I, [_P, C.c_long, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -500,6 +500,14 @@ static int run_block(vk_handle *h, const Block &b, const void *x, int N, int H, 
         y = (char *)y + (size_t)n0 * ho * wo * b.conv3.cout * es;
         N = nb;
     }
+    // res2: the whole block as one kernel (bneck_fused.hip) -- x is read once, t1 / t2 never leave the CU
+    if (h->dt == VK_F16 && !pool_part && b.conv1.stride == 1 && b.conv2.stride == 1 && b.conv2.dil == 1 && (!b.has_shortcut || b.fused_shortcut) &&
+        bneck_fused_eligible(b.conv1.cin, b.conv1.cout, b.conv3.cout, 1, b.conv2.groups, b.has_shortcut, N, H, W, h->dt)) {
+        if (Ho) *Ho = H;
+        if (Wo) *Wo = W;
+        return launch_bneck_fused(x, N, H, W, b.conv1.cin, b.has_shortcut, b.conv1.w, b.conv1.b, b.conv2.w, b.conv2.b, b.conv3.w, b.conv3.b, y,
+                                  cc, s);
+    }
     const void *res = x;
     if (b.has_shortcut && !b.fused_shortcut) {
         VK_TRY(run_conv(h, b.shortcut, x, N, H, W, nullptr, sc, false, h->dt, 0, s, nullptr, nullptr, nullptr, 0, nullptr, cc));
@@ -700,6 +708,14 @@ int vk_linear(const void *x, long M, int K, const void *w_packed, const float *b
     return launch_conv(a, (hipStream_t)stream);
 }
 
+int vk_bottleneck64(const void *x, int N, int H, int W, int cin, int proj, const void *w1, const float *b1, const void *w2,
+                    const float *b2, const void *w3, const float *b3, void *y, void *stream) {
+    VK_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && y && N > 0 && H > 0 && W > 0, VK_EINVAL, "bottleneck64: bad arguments");
+    VK_REQUIRE((cin == 256 && !proj) || (cin == 64 && proj), VK_EINVAL, "bottleneck64: cin must be 256 (identity) or 64 (projection)");
+    VK_REQUIRE((long)N * H * W * 512 < (1L << 31), VK_EINVAL, "bottleneck64: tensor beyond the 32-bit byte offsets");
+    return launch_bneck_fused(x, N, H, W, cin, proj != 0, w1, b1, w2, b2, w3, b3, y, false, (hipStream_t)stream);
+}
+
 size_t vk_conv1x1_meanpool_workspace_bytes(int N, int HW, int cout) { return conv_duo_pool_part_bytes((long)N * HW, cout); }
 
 int vk_conv1x1_meanpool(const void *x, int N, int HW, int cin, const void *w_packed, const float *bias_packed,
@@ -743,10 +759,10 @@ size_t vk_stem_workspace_bytes(int N, int H, int W, int cout, vk_dtype dt) {
 }
 
 static int stem_impl(const float *x, int N, int H, int W, const void *w, const float *b, int cout, int caffe, void *y,
-                     vk_dtype dt, void *img_pad, void *stem_out, hipStream_t s) {
+                     vk_dtype dt, void *img_pad, void *stem_out, hipStream_t s, int32_t *nonfinite = nullptr) {
     int H1, W1, Hp, Wp;
     stem_geom(H, W, &H1, &W1, &Hp, &Wp);
-    VK_TRY(launch_stem_pack(x, img_pad, N, H, W, Hp, Wp, dt, s));
+    VK_TRY(launch_stem_pack(x, img_pad, N, H, W, Hp, Wp, dt, s, nonfinite));
     if (stem_pool_eligible(cout, dt)) return launch_stem_pool(img_pad, N, Hp, Wp, H1, W1, w, b, caffe, y, s);
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1139,7 +1155,7 @@ int vk_forward_begin(vk_handle *h, const float *images_dev, int N, int H, int W,
 
     // ---- backbone (ResNet.forward frcnn.py:1076-1090) ----
     VK_TRY(stem_impl(images_dev, N, H, W, h->stem.w, h->stem.b, c.stem_out_channels, c.caffe_maxpool, p.bufA, h->dt,
-                     p.img_pad, p.stem_out, s));
+                     p.img_pad, p.stem_out, s, p.nonfinite));
     void *cur = p.bufA, *nxt = p.bufB;
     int ch = p.Hs[0], cw = p.Ws[0];
     // res4 at batch 32 is 2.05 rounds of tiles on 256 CUs: every N = 256 layer pays 3 rounds.  Its two half-batches run on

@@ -65,10 +65,11 @@ static inline int grid_for(long total, int block) {
 // x [N,3,H,W] f32 -> y [N,Hp,Wp,4] T; y[n, h+3, w+3, c] = x[n,c,h,w], everything else 0.
 template <typename T>
 __global__ void stem_pack_kernel(const float *__restrict__ x, T *__restrict__ y, int H, int W, int Hp, int Wp,
-                                 long total /* N*Hp*Wp */) {
+                                 long total /* N*Hp*Wp */, int *__restrict__ nonfinite) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long step = (long)gridDim.x * blockDim.x;
     const long HW = (long)H * W;
+    bool bad = false;
     for (; i < total; i += step) {
         int wp = (int)(i % Wp);
         long t = i / Wp;
@@ -81,11 +82,18 @@ __global__ void stem_pack_kernel(const float *__restrict__ x, T *__restrict__ y,
             v0 = s[0];
             v1 = s[HW];
             v2 = s[2 * HW];
+            // |v| < inf is false for inf and NaN.  (f16 mode: a finite pixel beyond the f16 range becomes inf in the cast below and
+            // is flagged as well: the conversion is what the stem convolves)
+            bad |= !(__builtin_fabsf((float)(T)v0) < INFINITY && __builtin_fabsf((float)(T)v1) < INFINITY && __builtin_fabsf((float)(T)v2) < INFINITY);
         }
         typedef T out4 __attribute__((ext_vector_type(4)));
         out4 o = {(T)v0, (T)v1, (T)v2, (T)0.f};
         reinterpret_cast<out4 *>(y)[i] = o;
     }
+    // A non-finite pixel makes the reference raise: the NaN / inf spreads through every convolution (torch's relu and max_pool2d
+    // keep NaN) into the RPN logits, torch.sort ranks NaN first, and _clip_box asserts on the selected boxes (frcnn.py:148).
+    // The ReLU epilogues here (v_max / v_pk_max) return the non-NaN operand, so the flag is raised at the source instead.
+    if (nonfinite && bad) atomicOr(nonfinite, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -224,13 +232,13 @@ __global__ __launch_bounds__(256) void mean_pool_kernel(const T *__restrict__ x,
 }
 
 // ---------------------------------------------------------------------------
-int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s) {
+int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s, int32_t *nonfinite) {
     long total = (long)N * Hp * Wp;
     int g = grid_for(total, 256);
     if (dt == VK_F16)
-        hipLaunchKernelGGL(stem_pack_kernel<_Float16>, dim3(g), dim3(256), 0, s, x, (_Float16 *)y, H, W, Hp, Wp, total);
+        hipLaunchKernelGGL(stem_pack_kernel<_Float16>, dim3(g), dim3(256), 0, s, x, (_Float16 *)y, H, W, Hp, Wp, total, nonfinite);
     else
-        hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(g), dim3(256), 0, s, x, (float *)y, H, W, Hp, Wp, total);
+        hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(g), dim3(256), 0, s, x, (float *)y, H, W, Hp, Wp, total, nonfinite);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
 }

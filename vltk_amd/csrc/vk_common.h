@@ -90,6 +90,10 @@ bool conv_ws_eligible(const ConvArgs &a);                 // conv_ws.hip (1x1, K
 int launch_conv_ws(const ConvArgs &a, hipStream_t stream);
 bool conv3x3_blk_eligible(const ConvArgs &a);             // conv3x3_blk.hip (narrow channel blocks: ResNeXt grouped 3x3, dense 64 -> 64)
 int launch_conv3x3_blk(const ConvArgs &a, hipStream_t stream);
+// bneck_fused.hip: a whole res2 BottleneckBlock (64 bottleneck channels, stride 1) as one kernel
+bool bneck_fused_eligible(int cin, int cmid, int cout, int stride, int groups, bool proj, long N, int H, int W, vk_dtype dt);
+int launch_bneck_fused(const void *x, int N, int H, int W, int cin, bool proj, const void *w1, const float *b1, const void *w2,
+                       const float *b2, const void *w3, const float *b3, void *y, bool concurrent, hipStream_t stream);
 bool conv_duo_dual_ok(const ConvArgs &a);
 bool conv_duo_pool_ok(const ConvArgs &a);                 // fused-mean form (pool_part set)
 size_t conv_duo_pool_part_bytes(long M, int Cout);
@@ -120,7 +124,7 @@ struct KernelTimer {
 extern thread_local KernelTimer *g_timer;
 
 // ---- pool.hip ----
-int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s);
+int launch_stem_pack(const float *x, void *y, int N, int H, int W, int Hp, int Wp, vk_dtype dt, hipStream_t s, int32_t *nonfinite = nullptr);
 int launch_maxpool(const void *x, void *y, int N, int H, int W, int C, int caffe, vk_dtype dt, hipStream_t s);
 bool stem_pool_eligible(int cout, vk_dtype dt);           // stem_pool.hip: 7x7 conv + BN + ReLU + max-pool as one kernel (f16, 64 channels)
 int launch_stem_pool(const void *x, int N, int Hp, int Wp, int H1, int W1, const void *w, const float *bias, int caffe, void *y,

@@ -237,13 +237,13 @@ class FRCNN:
 
     def kernel_timing(self, reset=False):
         """Per-bucket (launches, ms, algorithmic flops) of the conv launches since the last reset."""
-        n = (C.c_int64 * 11)()
-        ms = (C.c_double * 11)()
-        fl = (C.c_double * 11)()
-        by = (C.c_double * 11)()
+        n = (C.c_int64 * 12)()
+        ms = (C.c_double * 12)()
+        fl = (C.c_double * 12)()
+        by = (C.c_double * 12)()
         L.call("vk_get_kernel_timing", self._h, n, ms, fl, by, int(reset))
         names = ("conv_mfma256", "conv_mfma_f16", "conv_mfma_f16_f32out", "other", "conv3x3_panel", "conv_duo", "two_stream_backbone", "conv3x3_blk", "conv_ws",
-                 "conv_mfma256_dual", "conv_gemm4")
+                 "conv_mfma256_dual", "conv_gemm4", "bneck64")
         return {k: {"launches": int(n[i]), "ms": float(ms[i]), "flops": float(fl[i]), "bytes": float(by[i])}
                 for i, k in enumerate(names)}
 
