@@ -59,3 +59,23 @@ def test_gemm4_loop_has_no_compiler_valu():
     prod = {k: v for k, v in res.items() if "Lb0ELi0ELi" in k}     # <false, 0, TAG>
     assert prod, list(res)
     assert all(not v for v in prod.values()), {k: v[:4] for k, v in prod.items() if v}
+
+
+def test_scanner_follows_branches_to_labels_above_and_counts_every_vmem_instruction():
+    """(a) a hand-issued load pending at a branch to a label ABOVE (a loop back-edge, or hipcc placing a later block earlier in
+    the text) is carried to that label on the next pass; (b) stores and LDS-DMA pieces take places in the vmcnt queue;
+    (c) a 128-bit asm store needs `s_nop 1` behind it."""
+    code = ["s_branch .LBB0_2",
+            ".LBB0_1:", "v_mov_b32_e32 v20, v4",                       # reached from below with v[4:7] still in flight
+            "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v21, v5", "s_endpgm",
+            ".LBB0_2:", ";;#ASMSTART", "global_load_dwordx4 v[4:7], v[8:9], off", ";;#ASMEND", "s_branch .LBB0_1"]
+    assert [f[0] for f in chk.scan_function(code)] == [2]
+    q = [";;#ASMSTART", "global_load_dwordx4 v[4:7], v[8:9], off", ";;#ASMEND",
+         "global_load_lds_dwordx4 v10, s[2:3]",                         # an LDS-DMA piece: one place in the queue
+         ";;#ASMSTART", "global_store_dwordx4 v[8:9], v[12:15], off", "s_nop 1", ";;#ASMEND",
+         "s_waitcnt vmcnt(2)", "v_mov_b32_e32 v30, v4",                 # the load is the third youngest: retired
+         ";;#ASMSTART", "global_load_dwordx4 v[16:19], v[8:9], off", ";;#ASMEND",
+         "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v31, v16"]                # youngest of all: still pending
+    assert [f[0] for f in chk.scan_function(q)] == [14]
+    bad_store = [";;#ASMSTART", "global_store_dwordx4 v[8:9], v[12:15], off", ";;#ASMEND", "v_mov_b32_e32 v12, v1"]
+    assert len(chk.scan_function(bad_store)) == 1

@@ -37,92 +37,108 @@ def _regs(tok):
 def scan_function(lines):
     """lines: the instructions of one kernel.  Returns [(line_no, text, pending_read_line)].
 
-    The scan follows the text top to bottom and carries the queues of pending reads along FORWARD branches: the state at
-    an `s_branch` / `s_cbranch_*` is saved for its target label and merged in when the label is reached; after an
-    unconditional branch the fall-through text is unreachable, so it starts from what its own predecessors saved (hipcc lays
-    out a loop's exit block before the loop body, so a purely linear scan would see the exit block's loads as pending inside
-    the loop).  Backward branches (loop back-edges) are covered by the kernels' rule that every back-edge follows a
-    `s_waitcnt lgkmcnt(0)`: the state saved at a back-edge for an already-passed label must be empty, and is checked."""
-    pend, vpend, found = [], [], []          # in-flight LDS reads / in-flight global loads into registers (not LDS-DMA)
-    saved = {}                               # label -> (pend, vpend) carried by forward branches
-    passed = set()
-    reachable = True
-    in_asm = False                           # only HAND-ISSUED loads are tracked: hipcc waits correctly for its own
-
+    A small forward dataflow over the text: the queues of pending reads are carried along every branch -- the state at an
+    `s_branch` / `s_cbranch_*` is saved for its target label and merged in when the label is reached; after an unconditional
+    branch the fall-through text is unreachable and starts from what its predecessors saved (hipcc lays out a loop's exit block
+    before the loop body, and a later phase of a kernel before an earlier one, so a purely linear scan would be wrong both
+    ways).  Branches to labels ABOVE (loop back-edges, out-of-order block placement) are handled by repeating the scan with the
+    states they saved until nothing changes."""
     def merge(a, b):
         return sorted(set((i, frozenset(r)) for i, r in a) | set((i, frozenset(r)) for i, r in b))
 
-    for i, raw in enumerate(lines):
-        if "#ASMSTART" in raw:
-            in_asm = True
-        elif "#ASMEND" in raw:
-            in_asm = False
-        t = raw.split(";")[0].strip()
-        m = re.match(r"^(\.LBB\d+_\d+):", t)
-        if m:
-            lab = m.group(1)
-            sp, sv = saved.pop(lab, ([], []))
-            if reachable:
-                pend, vpend = merge(pend, sp), merge(vpend, sv)
-            else:
-                pend, vpend = merge([], sp), merge([], sv)
-            reachable = True
-            passed.add(lab)
-            continue
-        if not t or t.endswith(":") or t.startswith("."):
-            continue
-        parts = t.split(None, 1)
-        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
-        ops = [a.strip() for a in args.split(",")]
-        if op == "s_branch" or op.startswith("s_cbranch"):
-            lab = ops[0]
-            if lab in passed:                 # back-edge: nothing may be in flight (see the docstring)
-                for li, rs in list(pend) + list(vpend):
-                    if rs:
-                        found.append((i, t + "   [back-edge with a read in flight]", li))
-            else:
-                sp, sv = saved.get(lab, ([], []))
-                saved[lab] = (merge(sp, pend), merge(sv, vpend))
-            if op == "s_branch":
-                reachable = False
-                pend, vpend = [], []
-            continue
-        if op.startswith("ds_read"):
-            if in_asm:
-                pend.append((i, set(_regs(ops[0]))))
-            continue
-        if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", op):
-            # every vector-memory instruction takes a place in the in-order vmcnt queue (LDS-DMA pieces, stores and the compiler's
-            # own loads too: they carry no registers to watch, but `vmcnt(N)` counts them); only HAND-ISSUED loads into registers
-            # are watched
-            is_load_to_regs = "_load" in op and "_lds_" not in op and " lds" not in t
-            vpend.append((i, set(_regs(ops[0])) if (in_asm and is_load_to_regs) else set()))
-            continue
-        if op.startswith("s_waitcnt"):
-            m = re.search(r"lgkmcnt\((\d+)\)", t)
+    back = {}                                # label -> (pend, vpend) carried by branches from below (previous passes)
+    found_all = {}
+    for _pass in range(8):
+        pend, vpend, found = [], [], []      # in-flight LDS reads / the in-order queue of vector-memory instructions
+        saved = {}                           # label -> (pend, vpend) carried by forward branches
+        new_back = {}
+        passed = set()
+        reachable = True
+        in_asm = False                       # only HAND-ISSUED loads are watched: hipcc waits correctly for its own
+        for i, raw in enumerate(lines):
+            if "#ASMSTART" in raw:
+                in_asm = True
+            elif "#ASMEND" in raw:
+                in_asm = False
+            t = raw.split(";")[0].strip()
+            m = re.match(r"^(\.LBB\d+_\d+):", t)
             if m:
-                n = int(m.group(1))
-                if n == 0:
-                    pend = []
-                elif n < len(pend):
-                    pend = pend[len(pend) - n:]
-            m = re.search(r"vmcnt\((\d+)\)", t)
-            if m:          # the queue holds every vector-memory instruction in issue order, so the newest n stay pending
-                n = int(m.group(1))
-                if n == 0:
-                    vpend = []
-                elif n < len(vpend):
-                    vpend = vpend[len(vpend) - n:]
-            continue
-        if op.startswith("s_"):
-            continue
-        used = set()
-        for a in ops:
-            used |= set(_regs(a))
-        for li, rs in list(pend) + list(vpend):
-            if used & set(rs):
-                found.append((i, t, li))
-    return found
+                lab = m.group(1)
+                sp, sv = saved.pop(lab, ([], []))
+                bp, bv = back.get(lab, ([], []))
+                sp, sv = merge(sp, bp), merge(sv, bv)
+                if reachable:
+                    pend, vpend = merge(pend, sp), merge(vpend, sv)
+                else:
+                    pend, vpend = merge([], sp), merge([], sv)
+                reachable = True
+                passed.add(lab)
+                continue
+            if not t or t.endswith(":") or t.startswith("."):
+                continue
+            parts = t.split(None, 1)
+            op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+            ops = [a.strip() for a in args.split(",")]
+            if op == "s_branch" or op.startswith("s_cbranch"):
+                lab = ops[0]
+                if lab in passed:             # a label above: its state is merged in on the next pass
+                    sp, sv = new_back.get(lab, ([], []))
+                    new_back[lab] = (merge(sp, pend), merge(sv, vpend))
+                else:
+                    sp, sv = saved.get(lab, ([], []))
+                    saved[lab] = (merge(sp, pend), merge(sv, vpend))
+                if op == "s_branch":
+                    reachable = False
+                    pend, vpend = [], []
+                continue
+            if op.startswith("ds_read"):
+                if in_asm:
+                    pend.append((i, set(_regs(ops[0]))))
+                continue
+            if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", op):
+                # every vector-memory instruction takes a place in the in-order vmcnt queue (LDS-DMA pieces, stores and the
+                # compiler's own loads too: they carry no registers to watch, but `vmcnt(N)` counts them); only HAND-ISSUED
+                # loads into registers are watched
+                is_load_to_regs = "_load" in op and "_lds_" not in op and " lds" not in t
+                vpend.append((i, set(_regs(ops[0])) if (in_asm and is_load_to_regs) else set()))
+                if in_asm and "_store_dwordx" in op and re.search(r"dwordx[34]", op):
+                    # a 96- / 128-bit asm store reads its data registers over the states after issue and hipcc pads nothing
+                    # inside or behind an asm statement: the string must end with `s_nop 1` (bneck_fused.hip: a real bug)
+                    nxt = next((ln.split(";")[0].strip() for ln in lines[i + 1:i + 4] if ln.split(";")[0].strip() and "#ASM" not in ln), "")
+                    mm = re.match(r"s_nop\s+(\d+)", nxt)
+                    if not (mm and int(mm.group(1)) >= 1):
+                        found.append((i, t + "   [asm store without s_nop 1 behind it]", i))
+                continue
+            if op.startswith("s_waitcnt"):
+                m = re.search(r"lgkmcnt\((\d+)\)", t)
+                if m:
+                    n = int(m.group(1))
+                    if n == 0:
+                        pend = []
+                    elif n < len(pend):
+                        pend = pend[len(pend) - n:]
+                m = re.search(r"vmcnt\((\d+)\)", t)
+                if m:          # the queue holds every vector-memory instruction in issue order, so the newest n stay pending
+                    n = int(m.group(1))     # (merged paths: the union of their queues, which can only over-state what is pending)
+                    if n == 0:
+                        vpend = []
+                    elif n < len(vpend):
+                        vpend = vpend[len(vpend) - n:]
+                continue
+            if op.startswith("s_"):
+                continue
+            used = set()
+            for a in ops:
+                used |= set(_regs(a))
+            for li, rs in list(pend) + list(vpend):
+                if used & set(rs):
+                    found.append((i, t, li))
+        for f in found:
+            found_all[(f[0], f[2], f[1])] = f
+        if new_back == back:
+            break
+        back = new_back
+    return [found_all[k] for k in sorted(found_all)]
 
 
 def scan_asm_mfma_region(lines, min_states=20):

@@ -10,6 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvltk_hip.so")
+# tools only: the ablation build (make ABLATION=1 OUT=.../libvltk_hip_ablation.so) -- stamp / timing-only kernels, never the product
+if os.environ.get("VLTK_AMD_ABLATION_LIB") == "1":
+    LIB_PATH = LIB_PATH.replace("libvltk_hip.so", "libvltk_hip_ablation.so")
 
 VK_OK, VK_EINVAL, VK_ENOTIMPL, VK_ENONFINITE, VK_EWEIGHTS, VK_EHIP, VK_ENOMEM = range(7)
 VK_F32, VK_F16, VK_I64, VK_I32, VK_BF16 = 0, 1, 2, 3, 4

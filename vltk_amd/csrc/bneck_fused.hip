@@ -38,17 +38,19 @@ struct BneckK {
     int N, H, W;
     int tiles_x, tiles_y, ntiles;
     unsigned x_last;     // byte offset of the last pixel of x (loads of pixels outside the image are clamped to [0, x_last])
+    unsigned long *stamps;   // STAMP builds (make ABLATION=1, VK_BNECK_STAMPS=<file>): 8 words per wave
 };
 
 constexpr int BN_TH = 8, BN_TW = 32, BN_PH = 10, BN_PW = 34, BN_NP = BN_PH * BN_PW;   // 340 halo pixels
-constexpr int BN_CHPX = 32;                                   // halo pixels per ring chunk (two 16-pixel MFMA blocks)
-constexpr int BN_NCH = (BN_NP + BN_CHPX - 1) / BN_CHPX;       // 11 chunks per tile
-constexpr int BN_RING = 5;
+// ring chunks are 16 KB for both block kinds: 32 halo pixels of 256 channels (11 chunks per tile, ring of 5) or 128 pixels of 64
+// channels (3 chunks per tile, ring of 3 = a whole tile ahead)
+constexpr int bn_chpx(int cin) { return cin == 256 ? 32 : 128; }
+constexpr int bn_ring(int cin) { return cin == 256 ? 5 : 3; }
 constexpr int BN_T1_BYTES = BN_NP * 128, BN_T2_BYTES = BN_TH * BN_TW * 128;
 constexpr int BN_TRASH_BYTES = 1 << 16;
 
 template <int CIN>
-constexpr int bn_smem() { return BN_RING * BN_CHPX * CIN * 2 + BN_T1_BYTES + BN_T2_BYTES + 256 * 4; }   // + conv3's biases
+constexpr int bn_smem() { return bn_ring(CIN) * bn_chpx(CIN) * CIN * 2 + BN_T1_BYTES + BN_T2_BYTES + 384 * 4; }   // + the biases
 
 #define VKN_GLDS16(gptr, lptr)                                                                         \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),          \
@@ -65,14 +67,22 @@ __device__ __forceinline__ void bn_gload(half8 &dst, const char *addr) {
 }
 template <int OFF>
 __device__ __forceinline__ void bn_gstore(char *addr, half8 val) {
-    asm volatile("global_store_dwordx4 %0, %1, off offset:%2" ::"v"(addr), "v"(val), "n"(OFF) : "memory");
+    // s_nop 1: a 128-bit store reads its data registers over the two states after issue; hipcc does not pad an asm statement, and
+    // its next instruction may rewrite them (seen: dword 1 of some stores replaced by the next unit's sums)
+    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(addr), "v"(val), "n"(OFF) : "memory");
 }
 
 // CIN: channels of x (256: identity block; 64: block 0).  PROJ: conv3 and a projection shortcut as one GEMM, no residual.
-template <int CIN, bool PROJ>
+// STAMP: diagnostic build (tools only): core cycles of the three phases summed over a wave's tiles (s_memtime; the stamps
+// go to a buffer of their own and no output depends on them)
+template <int CIN, bool PROJ, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert((CIN == 256 && !PROJ) || (CIN == 64 && PROJ), "res2 shapes");
+    constexpr int BN_CHPX = bn_chpx(CIN), BN_RING = bn_ring(CIN);
+    constexpr int BN_NCH = (BN_NP + BN_CHPX - 1) / BN_CHPX;
+    constexpr int BPW = BN_CHPX / 32;             // 16-pixel blocks per wave and chunk
+    static_assert(BN_NCH >= BN_RING && 2 * BN_NCH > BN_NCH + BN_RING - 1, "the ring reaches at most into the next tile");
     constexpr int PXB = CIN * 2;                  // bytes per pixel of x
     constexpr int CHB = BN_CHPX * PXB;            // ring slot
     constexpr int SPP = PXB / 16;                 // 16-byte slots per pixel (32 / 8)
@@ -97,7 +107,6 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
     // consecutive channels (one 16-byte store / LDS write), as in conv_mfma.hip
     const int rowc = (j >> 2) * 8 + (j & 3);
     half8 w1f[2][KS1], w2f[2][9][2], w3f[4][2][KS3];
-    float b1v[8], b2v[8];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int co = cp * 32 + rowc + ni * 4;
@@ -115,12 +124,11 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
             for (int ks = 0; ks < KS3; ++ks) w3f[u][ni][ks] = *reinterpret_cast<const half8 *>(p.w3 + (long)c3 * (KS3 * 64) + (ks * 32 + g * 8) * 2);
         }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        b1v[e] = p.b1[cp * 32 + g * 8 + e];
-        b2v[e] = p.b2[cp * 32 + g * 8 + e];
+    B3[tid] = p.b3[tid];                          // biases in LDS: [conv3's 256 | conv1's 64 | conv2's 64] (48 registers per lane otherwise)
+    if (tid < 64) {
+        B3[256 + tid] = p.b1[tid];
+        B3[320 + tid] = p.b2[tid];
     }
-    B3[tid] = p.b3[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on vmcnt counts DMA pieces and hand-issued loads / stores only
     __syncthreads();
 
@@ -170,6 +178,16 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
     }
     int slot0 = 0;                                // ring slot of this tile's chunk 0
     bool first = true;
+    unsigned long st_a = 0, st_b = 0, st_c = 0, st_n = 0, st_t0 = 0, st_r0 = 0;
+    auto now = [&]() -> unsigned long {
+        unsigned long v = 0;
+        if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+        return v;
+    };
+    if constexpr (STAMP) {
+        st_t0 = now();
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0)::"memory");
+    }
     for (; t < t_end; t += nwx) {
         const int org = ((n * p.H + y0 - 1) * p.W + x0 - 1) * PXB;
         const int tn = t + nwx;
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
         const int c0 = j * 128 + ((g ^ (j & 7)) << 4);                        // phase C fragment / the lane's 16 B of a T2 row (slot g)
         const int wsl = ((cp * 4 + g) ^ (j & 7)) << 4;                        // T2 write: slot cp*4 + g of pixel j (16-aligned blocks)
 
+        const unsigned long s0 = now();
         // =========================== phase A: t1 = relu(conv1(x) + b1) on the halo ===========================
         // chunk c sits in slot (slot0 + c) % RING; at iteration c: wait for this wave's pieces of chunk c, barrier (publishes the
         // other waves' pieces; every wave is done with chunk c - 1), request chunk c + RING - 1 (of this tile or of the next) into
@@ -220,27 +239,31 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
                 }
             }
             const char *ch = smem + ((slot0 + c) % BN_RING) * CHB;
-            floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                const half8 xf = *reinterpret_cast<const half8 *>(ch + (a0 ^ (ks << 6)));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[0][ks], xf, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[1][ks], xf, acc1, 0, 0, 0);
-            }
-            // lane: halo pixel pp = c*32 + par*16 + j, channels cp*32 + g*8 .. +8
-            const int pp = c * BN_CHPX + par * 16 + j;
-            const int pr = pp / BN_PW, pc = pp - pr * BN_PW;
-            const bool inside = (unsigned)(y0 - 1 + pr) < (unsigned)p.H && (unsigned)(x0 - 1 + pc) < (unsigned)p.W;
-            half8 o;
+            for (int bw = 0; bw < BPW; ++bw) {       // this wave's blocks of the chunk: par, par + 2, ...
+                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v0 = acc0[e] + b1v[e], v1 = acc1[e] + b1v[4 + e];
-                v0 = v0 > 0.f ? v0 : 0.f;
-                v1 = v1 > 0.f ? v1 : 0.f;
-                o[e] = inside ? (_Float16)v0 : (_Float16)0.f;      // conv2's zero padding
-                o[4 + e] = inside ? (_Float16)v1 : (_Float16)0.f;
+                for (int ks = 0; ks < KS1; ++ks) {
+                    const half8 xf = *reinterpret_cast<const half8 *>(ch + bw * 32 * PXB + (a0 ^ (ks << 6)));
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[0][ks], xf, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[1][ks], xf, acc1, 0, 0, 0);
+                }
+                // lane: halo pixel pp, channels cp*32 + g*8 .. +8
+                const int pp = c * BN_CHPX + (par + 2 * bw) * 16 + j;
+                const int pr = pp / BN_PW, pc = pp - pr * BN_PW;
+                const bool inside = (unsigned)(y0 - 1 + pr) < (unsigned)p.H && (unsigned)(x0 - 1 + pc) < (unsigned)p.W;
+                half8 o;
+                const floatx4 ba = *reinterpret_cast<const floatx4 *>(B3 + 256 + cp * 32 + g * 8), bb = *reinterpret_cast<const floatx4 *>(B3 + 260 + cp * 32 + g * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v0 = acc0[e] + ba[e], v1 = acc1[e] + bb[e];
+                    v0 = v0 > 0.f ? v0 : 0.f;
+                    v1 = v1 > 0.f ? v1 : 0.f;
+                    o[e] = inside ? (_Float16)v0 : (_Float16)0.f;      // conv2's zero padding
+                    o[4 + e] = inside ? (_Float16)v1 : (_Float16)0.f;
+                }
+                if (pp < BN_NP) *reinterpret_cast<half8 *>(T1 + pp * 128 + (((cp * 4 + g) ^ (pc & 7)) << 4)) = o;
             }
-            if (pp < BN_NP) *reinterpret_cast<half8 *>(T1 + pp * 128 + (((cp * 4 + g) ^ (pc & 7)) << 4)) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // t1 is complete; the last chunk's slot is free
@@ -253,6 +276,38 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
                 request(org, BN_NCH - 1, sl);
         }
 
+        // Phase C's hand-issued loads run TWO blocks ahead, and the first two blocks' are issued here, ahead of phase B: an L2 /
+        // Infinity-Cache round trip is longer than a block of phase C, and with one wave per SIMD nothing else covers it (one
+        // block ahead, issued inside phase C: 14.9k cycles per tile for 2k cycles of MFMAs and ~5k of epilogue arithmetic).
+        half8 ld[3][NL];
+        char *ya[3];
+        auto addrs = [&](int i, const char *&xa_, char *&ya_) {
+            const int pb = par + 2 * i;
+            const int r = pb >> 1, cb = pb & 1;
+            const int oy = y0 + r, ox = x0 + cb * 16 + j;
+            const bool ok = oy < p.H && ox < p.W;
+            const int pix = (n * p.H + oy) * p.W + ox;
+            int xo = pix * PXB;
+            xo = min(max(xo, 0), (int)p.x_last);
+            xa_ = p.x + (unsigned)xo + g * 16 + (PROJ ? 0 : cp * 256);
+            ya_ = ok ? p.y + (long)pix * 512 + cp * 256 + g * 16 : p.trash + lq * 16 + cp * 256 + wave * 4096;
+        };
+        auto issue_loads = [&](int i, half8 (&d)[NL], char *&ya_) {
+            const char *xa_;
+            addrs(i, xa_, ya_);
+            if constexpr (PROJ) {
+                bn_gload<0>(d[0], xa_);
+                bn_gload<64>(d[1], xa_);
+            } else {
+                bn_gload<0>(d[0], xa_);
+                bn_gload<64>(d[1], xa_);
+                bn_gload<128>(d[2], xa_);
+                bn_gload<192>(d[3], xa_);
+            }
+        };
+        issue_loads(0, ld[0], ya[0]);
+        issue_loads(1, ld[1], ya[1]);
+        const unsigned long s1 = now();
         // =========================== phase B: t2 = relu(conv2(t1) + b2), 3x3, nine shifted reads of t1 ===========================
         // this wave's blocks: pb = par + 2 i (i = 0 .. 7), block pb = tile row pb >> 1, columns (pb & 1) * 16 .. + 15; fragment
         // reads run one tap row ahead of the MFMAs in two register sets (conv3x3_blk.hip)
@@ -281,9 +336,10 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
             auto out = [&](int i) {
                 const int pb = par + 2 * i;
                 half8 o;
+                const floatx4 ba = *reinterpret_cast<const floatx4 *>(B3 + 320 + cp * 32 + g * 8), bb = *reinterpret_cast<const floatx4 *>(B3 + 324 + cp * 32 + g * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v0 = acc0[e] + b2v[e], v1 = acc1[e] + b2v[4 + e];
+                    float v0 = acc0[e] + ba[e], v1 = acc1[e] + bb[e];
                     v0 = v0 > 0.f ? v0 : 0.f;
                     v1 = v1 > 0.f ? v1 : 0.f;
                     o[e] = (_Float16)v0;
@@ -323,53 +379,31 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();               // t2 is complete (both channel halves of every pixel)
 
+        const unsigned long s2 = now();
         // =========================== phase C: y = relu(conv3(t2) [+ shortcut(x)] + b3 [+ x]) -> HBM ===========================
         // blocks as in phase B; output channels cp*128 + u*32 .. (u = 0 .. 3).  Per block NL hand-issued loads (identity: the
-        // residual's four 16-byte pieces per lane; PROJ: the two x fragments of the shortcut) one block ahead, and 4 stores.
+        // residual's four 16-byte pieces per lane; PROJ: the two x fragments of the shortcut) two blocks ahead, and 4 stores.
         {
-            half8 ld[2][NL];
-            char *ya[2];
-            auto addrs = [&](int i, const char *&xa_, char *&ya_) {
-                const int pb = par + 2 * i;
-                const int r = pb >> 1, cb = pb & 1;
-                const int oy = y0 + r, ox = x0 + cb * 16 + j;
-                const bool ok = oy < p.H && ox < p.W;
-                const int pix = (n * p.H + oy) * p.W + ox;
-                int xo = pix * PXB;
-                xo = min(max(xo, 0), (int)p.x_last);
-                xa_ = p.x + (unsigned)xo + g * 16 + (PROJ ? 0 : cp * 256);
-                ya_ = ok ? p.y + (long)pix * 512 + cp * 256 + g * 16 : p.trash + lq * 16 + cp * 256 + wave * 4096;
-            };
-            auto issue_loads = [&](int i, half8 (&d)[NL], char *&ya_) {
-                const char *xa_;
-                addrs(i, xa_, ya_);
-                if constexpr (PROJ) {
-                    bn_gload<0>(d[0], xa_);
-                    bn_gload<64>(d[1], xa_);
-                } else {
-                    bn_gload<0>(d[0], xa_);
-                    bn_gload<64>(d[1], xa_);
-                    bn_gload<128>(d[2], xa_);
-                    bn_gload<192>(d[3], xa_);
-                }
-            };
-            issue_loads(0, ld[0], ya[0]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                half8(&cur)[NL] = ld[i & 1];
-                if (i + 1 < 8) issue_loads(i + 1, ld[(i + 1) & 1], ya[(i + 1) & 1]);
+                half8(&cur)[NL] = ld[i % 3];
+                if (i + 2 < 8) issue_loads(i + 2, ld[(i + 2) % 3], ya[(i + 2) % 3]);
                 const int pb = par + 2 * i;
                 const half8 t0 = *reinterpret_cast<const half8 *>(T2 + pb * 16 * 128 + c0);
                 const half8 t1 = *reinterpret_cast<const half8 *>(T2 + pb * 16 * 128 + (c0 ^ 64));
-                // younger than this block's loads: the next block's NL loads, the previous block's 4 stores (i > 0), and
-                // this block's own stores so far
+                // issue order of a wave's phase-C instructions: L0 L1 | L2 S0 | L3 S1 | ... | L7 S5 | S6 | S7 (Li: the NL loads of
+                // block i, Si: its 4 stores).  Behind block i's loads when they are needed: nL later load blocks (2; block 6: 1;
+                // block 7: 0) and nS earlier store blocks (0, 1, then 2)
+                const int nL = i <= 5 ? 2 : 7 - i, nS = i < 2 ? i : 2;
                 if constexpr (PROJ) {
-                    if (i == 0)
-                        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur[0]), "+v"(cur[1]) : "n"(NL) : "memory");
-                    else if (i < 7)
-                        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur[0]), "+v"(cur[1]) : "n"(NL + 4) : "memory");
+                    if (NL * nL + 4 * nS == 4)
+                        asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
+                    else if (NL * nL + 4 * nS == 8)
+                        asm volatile("s_waitcnt vmcnt(8)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
+                    else if (NL * nL + 4 * nS == 10)
+                        asm volatile("s_waitcnt vmcnt(10)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
                     else
-                        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cur[0]), "+v"(cur[1]) : "n"(4) : "memory");
+                        asm volatile("s_waitcnt vmcnt(12)" : "+v"(cur[0]), "+v"(cur[1])::"memory");
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -387,22 +421,21 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
                     const float *bl = B3 + cp * 128 + u * 32 + g * 8;
                     floatx4 v0 = acc0 + *reinterpret_cast<const floatx4 *>(bl), v1 = acc1 + *reinterpret_cast<const floatx4 *>(bl + 4);
                     if constexpr (!PROJ) {
-                        // residual piece u of this block: younger = the other pieces behind it (3 - u), the next block's loads,
-                        // the previous block's stores, this block's stores so far (u)
                         half8 &rr = cur[u];
-                        if (i == 0)
-                            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr) : "n"(3 + NL) : "memory");
-                        else if (i < 7)
-                            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr) : "n"(3 + NL + 4) : "memory");
+                        // piece u: + the 3 - u pieces behind it + this block's u stores so far = 3 more
+                        if (3 + 4 * (nL + nS) == 11)
+                            asm volatile("s_waitcnt vmcnt(11)" : "+v"(rr)::"memory");
+                        else if (3 + 4 * (nL + nS) == 15)
+                            asm volatile("s_waitcnt vmcnt(15)" : "+v"(rr)::"memory");
                         else
-                            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr) : "n"(3 + 4) : "memory");
+                            asm volatile("s_waitcnt vmcnt(19)" : "+v"(rr)::"memory");
                         v0 += __builtin_convertvector(__builtin_shufflevector(rr, rr, 0, 1, 2, 3), floatx4);
                         v1 += __builtin_convertvector(__builtin_shufflevector(rr, rr, 4, 5, 6, 7), floatx4);
                     }
                     const half4 h0 = __builtin_convertvector(v0, half4), h1 = __builtin_convertvector(v1, half4);
                     half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                     o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    char *ya_ = ya[i & 1];
+                    char *ya_ = ya[i % 3];
                     if (u == 0) bn_gstore<0>(ya_, o);
                     if (u == 1) bn_gstore<64>(ya_, o);
                     if (u == 2) bn_gstore<128>(ya_, o);
@@ -412,6 +445,13 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
         }
         // (T2 is rewritten only in the next tile's phase B, T1 in its phase A: both behind barriers every wave passes after
         //  finishing this phase)
+        if constexpr (STAMP) {
+            const unsigned long s3 = now();
+            st_a += s1 - s0;
+            st_b += s2 - s1;
+            st_c += s3 - s2;
+            st_n += 1;
+        }
         slot0 = (slot0 + BN_NCH) % BN_RING;
         n = nn;
         y0 = ny0;
@@ -419,6 +459,20 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
         first = false;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the padding requests of the last tile land before the LDS is released
+    if constexpr (STAMP) {
+        const unsigned long t1_ = now();
+        unsigned long r1_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1_)::"memory");
+        if (lane == 0) {
+            unsigned long *o = p.stamps + ((long)blockIdx.x * 4 + wave) * 8;
+            o[0] = st_a;
+            o[1] = st_b;
+            o[2] = st_c;
+            o[3] = st_n;
+            o[4] = t1_ - st_t0;      // whole kernel, core cycles
+            o[5] = r1_ - st_r0;      // whole kernel, 10 ns ticks
+        }
+    }
 }
 
 bool bneck_fused_eligible(int cin, int cmid, int cout, int stride, int groups, bool proj, long N, int H, int W, vk_dtype dt) {
@@ -466,6 +520,35 @@ int launch_bneck_fused(const void *x, int N, int H, int W, int cin, bool proj, c
     k.ntiles = (int)nt;
     k.x_last = (unsigned)(((long)N * H * W - 1) * cin * 2);
     const int grid = n_cu[dev];                   // a multiple of 8: every XCD walks its own range of tiles
+    k.stamps = nullptr;
+#ifdef VK_ABLATION
+    if (const char *sf = getenv("VK_BNECK_STAMPS")) {     // diagnostic: one stamped launch, 8 words per wave appended to the file
+        const size_t nb = (size_t)grid * 4 * 8 * sizeof(unsigned long);
+        VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
+        VK_CHECK_HIP(hipMemsetAsync(k.stamps, 0, nb, stream));
+        if (proj) {
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_kernel<64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bn_smem<64>()));
+            hipLaunchKernelGGL((bneck64_kernel<64, true, true>), dim3(grid), dim3(256), bn_smem<64>(), stream, k);
+        } else {
+            VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_kernel<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bn_smem<256>()));
+            hipLaunchKernelGGL((bneck64_kernel<256, false, true>), dim3(grid), dim3(256), bn_smem<256>(), stream, k);
+        }
+        VK_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long> hst((size_t)grid * 4 * 8);
+        VK_CHECK_HIP(hipMemcpy(hst.data(), k.stamps, nb, hipMemcpyDeviceToHost));
+        VK_CHECK_HIP(hipFree(k.stamps));
+        if (FILE *f = fopen(sf, "a")) {
+            fprintf(f, "# wg wave phaseA phaseB phaseC tiles kernel_cycles kernel_ticks(10ns)  proj=%d\n", (int)proj);
+            for (int w = 0; w < grid * 4; ++w) {
+                fprintf(f, "%d %d", w / 4, w % 4);
+                for (int i = 0; i < 6; ++i) fprintf(f, " %lu", hst[(size_t)w * 8 + i]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        return VK_OK;
+    }
+#endif
     KernelTimer *tm = g_timer;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (tm) {
