@@ -98,12 +98,15 @@ def run_layers(x, p, proj):
     return y
 
 
+@pytest.mark.parametrize("form", ["rows", "tiles"])
 @pytest.mark.parametrize("proj", [False, True], ids=["identity", "projection"])
-@pytest.mark.parametrize("shape", [(2, 16, 64), (1, 8, 32), (3, 13, 45), (2, 40, 70), (1, 5, 7), (1, 200, 333)],
+@pytest.mark.parametrize("shape", [(2, 16, 64), (1, 8, 32), (3, 13, 45), (2, 40, 70), (1, 5, 7), (1, 1, 1), (2, 3, 31), (1, 67, 30), (1, 200, 333)],
                          ids=lambda s: "x".join(map(str, s)))
-def test_bottleneck64_vs_reference_and_layers(shape, proj):
-    """Whole tiles, one tile, ragged edges in both directions (8 x 32 tiles against 13 x 45 / 40 x 70), an image smaller than
-    a tile, and the real res2 map of an 800 x 1333 image (200 x 333: 25 x 11 tiles, the last tile column 13 pixels wide)."""
+def test_bottleneck64_vs_reference_and_layers(shape, proj, form, monkeypatch):
+    """Both forms of the kernel (row-streaming column strips, the default; 8 x 32 tiles): whole strips / tiles, ragged edges in both
+    directions, images smaller than a strip or a tile (down to one pixel), a strip of exactly 30 columns, several row units, and
+    the real res2 map of an 800 x 1333 image (200 x 333: 12 strips of 28 columns / 25 x 11 tiles)."""
+    monkeypatch.setenv("VK_BNECK_ROWS", "1" if form == "rows" else "0")
     N, H, W = shape
     cin = 64 if proj else 256
     g = np.random.Generator(np.random.PCG64(H * 1000 + W))
@@ -125,10 +128,12 @@ def test_bottleneck64_vs_reference_and_layers(shape, proj):
     assert same, "fused block != layer-by-layer kernels"
 
 
-def test_bottleneck64_many_tiles_reproducible():
-    """Several tiles per workgroup (the ring runs across tiles, ring slot phase changes from tile to tile: 11 chunks mod 5 slots)
-    at batch size: 8 images of the real res2 map = 2200 tiles on 256 workgroups; twice, bit-identical, and equal to the
+@pytest.mark.parametrize("form", ["rows", "tiles"])
+def test_bottleneck64_many_tiles_reproducible(form, monkeypatch):
+    """Several units per workgroup (the tile form's ring runs across tiles and changes slot phase from tile to tile; the row form
+    restarts its pipeline per unit) at batch size: 8 images of the real res2 map; twice, bit-identical, and equal to the
     layer-by-layer kernels."""
+    monkeypatch.setenv("VK_BNECK_ROWS", "1" if form == "rows" else "0")
     g = np.random.Generator(np.random.PCG64(5))
     x = F.relu(torch.from_numpy(g.standard_normal((8, 256, 200, 333)).astype(np.float32)))
     p = make_block(3, 256, False)

@@ -50,11 +50,16 @@ for proj in (False, True):
     for _ in range(3):
         fused(), layers()
     torch.cuda.synchronize()
-    tf, tl = [], []
+    tf, tl, tt = [], [], []
     for _ in range(reps):
+        os.environ["VK_BNECK_ROWS"] = "1"
         tf.append(timed(fused))
+        os.environ["VK_BNECK_ROWS"] = "0"
+        tt.append(timed(fused))
         tl.append(timed(layers))
+    os.environ["VK_BNECK_ROWS"] = "1"
+    fused()
     px = B * H * W
     byt = px * (cin * 2 + 512)
-    print(f"res2 block {'0 (projection, cin 64)' if proj else '1/2 (identity, cin 256)'} batch {B}: fused {np.median(tf):8.1f} us (min {min(tf):8.1f}) = "
-          f"{byt / np.median(tf) / 1e6:.2f} TB/s of x-in + y-out | layer by layer {np.median(tl):8.1f} us (min {min(tl):8.1f}) | equal: {torch.equal(y, y2)}")
+    print(f"res2 block {'0 (projection, cin 64)' if proj else '1/2 (identity, cin 256)'} batch {B}: fused rows {np.median(tf):8.1f} us (min {min(tf):8.1f}) = "
+          f"{byt / np.median(tf) / 1e6:.2f} TB/s of x-in + y-out | fused tiles {np.median(tt):8.1f} us | layer by layer {np.median(tl):8.1f} us (min {min(tl):8.1f}) | equal: {torch.equal(y, y2)}")

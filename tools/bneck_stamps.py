@@ -19,7 +19,9 @@ import test_gpu_bneck_fused as T                       # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 H, W = 200, 333
-for proj in (False, True):
+DBGS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]      # rows form, identity block: VK_BNECK_DBG ablations
+for proj, dbg in [(False, d) for d in DBGS] + [(True, 0)]:
+    os.environ["VK_BNECK_DBG"] = str(dbg)
     cin = 64 if proj else 256
     g = np.random.Generator(np.random.PCG64(1))
     xd = torch.from_numpy(g.standard_normal((B, H, W, cin)).astype(np.float16)).to(G.DEV).relu_()
@@ -44,5 +46,5 @@ for proj in (False, True):
     rows = np.array([[float(v) for v in ln.split()] for ln in open(path) if not ln.startswith("#")])
     a, b, c, n, cyc, ticks = (rows[:, i] for i in range(2, 8))
     clock = np.median(cyc / ticks) * 0.1
-    print(f"proj={proj}: clock {clock:.2f} GHz; per tile (median over waves, core cycles): phase A {np.median(a / n):.0f}  B {np.median(b / n):.0f}  "
+    print(f"proj={proj} dbg={dbg}: clock {clock:.2f} GHz; per tile (median over waves, core cycles): phase A {np.median(a / n):.0f}  B {np.median(b / n):.0f}  "
           f"C {np.median(c / n):.0f}  sum {np.median((a + b + c) / n):.0f}; tiles per wave {np.median(n):.0f}; kernel {np.median(ticks) / 100:.1f} us")

@@ -17,7 +17,9 @@
 // Residual reads and output stores are hand-issued (asm) so that their waits can be counted: hipcc waits vmcnt(0) for any load
 // it sees while LDS-DMA is in flight.  Lanes whose pixel is outside the image load from a clamped address and store to a
 // scratch page, so every wave issues the same number of vector-memory instructions and the static counts hold.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "vk_common.h"
 
@@ -475,6 +477,286 @@ __global__ __launch_bounds__(256, 1) void bneck64_kernel(BneckK p) {
     }
 }
 
+
+// =====================================================================================================================
+// ROW-STREAMING form (the default): the tile form above re-reads x for the residual and reads a 10 x 34 halo per 8 x 32 outputs:
+// 3.6 GB through the fabric per identity block at bench size against 2.2 GB of x-in + y-out, and its time is exactly that
+// traffic at ~6 TB/s (stamps: phase A waits for LDS-DMA, phase C for the residual).  Here a unit of work is a COLUMN STRIP:
+// <= 30 output columns (+ 1 halo column each side = one 32-pixel row of x = two MFMA blocks) x RU rows, walked row by row:
+//   step s:  x halo row s arrives (LDS-DMA, P rows ahead, ring of R = P + 4 rows)
+//            A: conv1 on x row s            -> t1 row s        (ring of 4 rows in LDS)
+//            B: 3x3 on t1 rows s-3 .. s-1   -> t2 row s-3      (2 rows in LDS)
+//            C: conv3 on t2 row s-4 + residual = x row s-3, STILL IN THE RING -> y row s-4 -> HBM
+// The three parts of a step only use what earlier steps published: ONE barrier per step, and hipcc is free to interleave
+// them.  x is read once (32 / TW columns per output column, two extra rows per unit), nothing else is read: the only
+// hand-issued vector-memory instructions are the stores, and every step issues the same number of them (to the scratch page
+// while the pipeline fills and drains), so the one counted wait per step is static.
+struct BneckRowsK {
+    const char *x, *w1, *w2, *w3;
+    const float *b1, *b2, *b3;
+    char *y, *trash;
+    int N, H, W;
+    int strips, tw;          // column strips per image and their width (<= 30)
+    int vsplit, ru;          // row units per strip and their height
+    int nunits;
+    unsigned long *stamps;
+};
+
+constexpr int BR_P = 3;                          // x rows in flight ahead of the row being multiplied
+constexpr int BR_R = BR_P + 4;                   // x-row ring: row s is last read (residual) at step s + 3
+constexpr int BR_T1_ROW = 32 * 128, BR_T1_BYTES = 4 * BR_T1_ROW + 256, BR_T2_BYTES = 2 * 32 * 128;
+template <int CIN>
+constexpr int br_smem() { return BR_R * 32 * CIN * 2 + BR_T1_BYTES + BR_T2_BYTES + 384 * 4; }
+
+// EIGHT waves (two per SIMD): wave = (cq, par) = (a quarter of the channels, one of the row's two 16-pixel blocks).  With four
+// waves (one per SIMD, the tile form's split) a step took ~4000 cycles for 1100 cycles of MFMAs: a wave alone issues one vector
+// instruction per 4 cycles, half of the weights sat in AGPRs behind v_accvgpr_read, and nothing covered LDS round trips.  With
+// eight, a wave's weights are 136 registers (A and B: ONE 16-channel MFMA tile, C: 64 output channels), the SIMD interleaves
+// two instruction streams, and the fragments a wave reads from LDS feed one MFMA instead of two (LDS ~1100 cycles per step).
+// DBG (tools build only; WRONG results): timing-only ablations: 1 no A, 2 no B, 4 no C arithmetic, 8 no stores, 16 no DMA
+template <int CIN, bool PROJ, bool STAMP = false, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void bneck64_rows_kernel(BneckRowsK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert((CIN == 256 && !PROJ) || (CIN == 64 && PROJ), "res2 shapes");
+    constexpr int PXB = CIN * 2;                  // bytes per pixel of x
+    constexpr int XROW = 32 * PXB;                // one x row of the strip (16 KB / 4 KB)
+    constexpr int SPP = PXB / 16;                 // 16-byte slots per pixel (32 / 8)
+    constexpr int KM = SPP == 32 ? 15 : 7;        // swizzle key mask: slot' = slot ^ (pixel & KM)
+    constexpr int PPI = 64 / SPP;                 // pixels per DMA instruction (2 / 8)
+    constexpr int NI = 32 / PPI;                  // DMA instructions per row (16 / 4): wave w issues NI / 8 of them (2; PROJ: waves 0-3 one)
+    constexpr int NQ = NI >= 8 ? NI / 8 : 1;
+    constexpr int KS1 = CIN / 32;
+    constexpr int KS3 = PROJ ? 4 : 2;
+    char *const T1 = smem + BR_R * XROW;
+    char *const T2 = T1 + BR_T1_BYTES;
+    float *const BI = reinterpret_cast<float *>(T2 + BR_T2_BYTES);     // [conv3's 256 | conv1's 64 | conv2's 64] biases
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cq = wave & 3, par = wave >> 2;
+    const bool dma_wave = NI >= 8 || wave < NI;   // PROJ: a row is four DMA instructions
+    // ---- weights: registers, for the lifetime of the workgroup ----
+    // A, B: MFMA row j = channel cq*16 + j (a lane ends up with 4 consecutive channels: 8 bytes).  C: row j of tile ni of unit u
+    // = channel cq*64 + u*32 + (j>>2)*8 + ni*4 + (j&3) (8 consecutive channels per lane: one 16-byte store)
+    half8 w1f[KS1], w2f[9][2], w3f[2][2][KS3];
+    {
+        const int g = lane >> 4, j = lane & 15;
+        const int co = cq * 16 + j;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) w1f[ks] = *reinterpret_cast<const half8 *>(p.w1 + (long)co * PXB + (ks * 32 + g * 8) * 2);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) w2f[tap][ks] = *reinterpret_cast<const half8 *>(p.w2 + (long)co * (9 * 64 * 2) + (tap * 64 + ks * 32 + g * 8) * 2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int c3 = cq * 64 + u * 32 + (j >> 2) * 8 + ni * 4 + (j & 3);
+#pragma unroll
+                for (int ks = 0; ks < KS3; ++ks) w3f[u][ni][ks] = *reinterpret_cast<const half8 *>(p.w3 + (long)c3 * (KS3 * 64) + (ks * 32 + g * 8) * 2);
+            }
+    }
+    if (tid < 256) BI[tid] = p.b3[tid];
+    if (tid < 64) {
+        BI[256 + tid] = p.b1[tid];
+        BI[320 + tid] = p.b2[tid];
+    }
+    // the row behind the T1 ring that taps of the two padding columns (outputs 30, 31: never stored) read
+    if (tid < 16) reinterpret_cast<floatx4 *>(T1 + 4 * BR_T1_ROW)[tid] = floatx4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on vmcnt counts DMA pieces and hand-issued stores only
+    __syncthreads();
+
+    unsigned long st_w = 0, st_n = 0, st_t0 = 0, st_r0 = 0;
+    auto now = [&]() -> unsigned long {
+        unsigned long v = 0;
+        if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+        return v;
+    };
+    if constexpr (STAMP) {
+        st_t0 = now();
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0)::"memory");
+    }
+
+    // ---- this workgroup's units: 8 contiguous ranges of the unit list (one per XCD), walked together by its workgroups ----
+    const int xcd = blockIdx.x & 7, wgx = blockIdx.x >> 3, nwx = gridDim.x >> 3;
+    const int rlen = (p.nunits + 7) >> 3;
+    const int u_end = min((xcd + 1) * rlen, p.nunits);
+    int lq = lane;
+    for (int unit = xcd * rlen + wgx; unit < u_end; unit += nwx) {
+        asm volatile("" : "+v"(lq));                  // per-lane offsets are recomputed per unit (see the tile form)
+        const int g = lq >> 4, j = lq & 15;
+        // unit -> (image, row unit, strip): strips of one row unit are neighbours in the list (they share halo columns)
+        const int strip = unit % p.strips, vu = (unit / p.strips) % p.vsplit, n = unit / (p.strips * p.vsplit);
+        const int x0 = strip * p.tw, y0 = vu * p.ru;
+        const int tw = min(p.tw, p.W - x0), ru = min(p.ru, p.H - y0);       // this unit's outputs: ru rows x tw columns
+        // ---- per-lane offsets ----
+        const int pcA = par * 16 + j;                                       // this lane's halo column in A (x / t1 pixel of the row)
+        const int aoff = pcA * PXB + ((g ^ (pcA & KM)) << 4);                // A fragment: ^ (ks << 6)
+        // t1 / t2 writes: 4 channels cq*16 + g*4 .. = bytes cq*32 + g*8 of the pixel: 16-byte slot cq*2 + (g>>1), half g&1
+        const int t1w = pcA * 128 + (((cq * 2 + (g >> 1)) ^ (pcA & 7)) << 4) + (g & 1) * 8;
+        const bool colA = (unsigned)(x0 - 1 + pcA) < (unsigned)p.W;         // halo column inside the image
+        const int c = par * 16 + j;                                         // this lane's output column in B / C
+        int colb[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) colb[dx] = (c + dx) * 128 + ((g ^ ((c + dx) & 7)) << 4);
+        const int t2w = c * 128 + (((cq * 2 + (g >> 1)) ^ (c & 7)) << 4) + (g & 1) * 8;
+        const int t2r = c * 128 + ((g ^ (c & 7)) << 4);                      // ^ 64 for the second K step
+        // x centre pixel of output column c.  Identity: the residual's channels cq*64 + u*32 + g*8 = slot cq*8 + u*4 + g (^ u << 6);
+        // PROJ: the shortcut's K step ks = slot ks*4 + g (^ ks << 6)
+        const int xr = PROJ ? (c + 1) * PXB + ((g ^ ((c + 1) & 7)) << 4)
+                            : (c + 1) * PXB + (cq >> 1) * 256 + ((((cq & 1) * 8 + g) ^ ((c + 1) & 15)) << 4);
+        const bool colC = c < tw;                                           // (x0 + c < W follows from tw)
+        const long ycol = (long)(x0 + c) * 512 + cq * 128 + g * 16;
+        char *const ytrash = p.trash + lq * 16 + wave * 2048;
+        // DMA: piece q of this wave covers pixels (wave*NQ + q)*PPI + lane / SPP of the row; the column is clamped into the image
+        int dcol[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pic = ((wave * NQ + q) * PPI + lq / SPP) & 31;
+            const int col = min(max(x0 - 1 + pic, 0), p.W - 1);
+            dcol[q] = col * PXB + (((lq % SPP) ^ (pic & KM)) << 4);
+        }
+        const long img = (long)n * p.H * p.W;
+        auto request = [&](int h) {                  // x halo row h of this unit (image row y0 - 1 + h, clamped) -> ring slot h % R
+            if (!dma_wave || (DBG & 16)) return;
+            const int yy = min(max(y0 - 1 + h, 0), p.H - 1);
+            const unsigned rowb = (unsigned)((img + (long)yy * p.W) * PXB);
+            const int sl = h % BR_R;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) VKN_GLDS16(p.x + (rowb + (unsigned)dcol[q]), smem + sl * XROW + (wave * NQ + q) * 1024);
+        };
+#pragma unroll
+        for (int h = 0; h < BR_P; ++h) request(h);
+        const int nsteps = ru + 4;                   // halo rows 0 .. ru + 1 (A), output rows behind them: B three steps, C four
+#pragma clang loop unroll(disable)
+        for (int s = 0; s < nsteps; ++s) {
+            const unsigned long sw0 = now();
+            // row s's pieces: younger are the 2 stores of step s - P and the pieces + stores of steps s - P + 1 .. s - 1; in the first
+            // P steps of a unit: the rest of the prologue's rows and the pieces + stores of the steps so far.  (PROJ: waves 4 - 7
+            // request nothing and wait for nothing; the barrier publishes the others' rows.)
+            static_assert(BR_P == 3, "the first-step counts below are written for P = 3");
+            if (dma_wave && !(DBG & 24)) {
+                if (s >= BR_P)
+                    bn_vm_wait<2 + (BR_P - 1) * (NQ + 2)>();
+                else if (s == 0)
+                    bn_vm_wait<(BR_P - 1) * NQ>();
+                else if (s == 1)
+                    bn_vm_wait<(BR_P - 2) * NQ + (NQ + 2)>();
+                else
+                    bn_vm_wait<(BR_P - 3) * NQ + 2 * (NQ + 2)>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if constexpr (STAMP) st_w += now() - sw0;
+            request(s + BR_P);                       // (beyond the unit's last halo row: a clamped row nobody reads; same count)
+
+            // The three parts run UNCONDITIONALLY (while the pipeline fills and drains they work on rows nobody reads and C stores to
+            // the scratch page), so a step is straight-line code for hipcc to interleave across the parts.
+            const char *xrow = smem + (s % BR_R) * XROW;
+            const char *t2row = T2 + ((s + 1) & 1) * (32 * 128);       // written at step s - 1
+            const char *xres = smem + ((s + BR_R - 3) % BR_R) * XROW;  // x row s - 3: the residual / shortcut input of output row s - 4
+            // ---- A: t1 row s = relu(conv1(x row s) + b1), zero outside the image (conv2's padding) ----
+            if constexpr (!(DBG & 1)) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[ks], *reinterpret_cast<const half8 *>(xrow + (aoff ^ (ks << 6))), acc, 0, 0, 0);
+                const bool inside = colA && (unsigned)(y0 - 1 + s) < (unsigned)p.H;
+                const floatx4 ba = *reinterpret_cast<const floatx4 *>(BI + 256 + cq * 16 + g * 4);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[e] + ba[e];
+                    v = v > 0.f ? v : 0.f;
+                    o[e] = inside ? (_Float16)v : (_Float16)0.f;
+                }
+                *reinterpret_cast<half4 *>(T1 + (s & 3) * BR_T1_ROW + t1w) = o;
+            }
+            // ---- B: t2 row s - 3 = relu(conv2(t1 rows s-3 .. s-1) + b2) ----
+            if constexpr (!(DBG & 2)) {
+                floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const char *rowp = T1 + ((s - 3 + dy) & 3) * BR_T1_ROW;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[dy * 3 + dx][ks], *reinterpret_cast<const half8 *>(rowp + (colb[dx] ^ (ks << 6))), acc, 0, 0, 0);
+                }
+                const floatx4 ba = *reinterpret_cast<const floatx4 *>(BI + 320 + cq * 16 + g * 4);
+                half4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[e] + ba[e];
+                    v = v > 0.f ? v : 0.f;
+                    o[e] = (_Float16)v;
+                }
+                *reinterpret_cast<half4 *>(T2 + (s & 1) * (32 * 128) + t2w) = o;
+            }
+            // ---- C: y row s - 4 = relu(conv3(t2 row s-4) [+ shortcut(x row s-3)] + b3 [+ x row s-3]) -> HBM ----
+            {
+                const bool live = s >= 4 && s <= ru + 3;               // otherwise: same instructions, stores to the scratch page
+                char *yrow = (live && colC) ? p.y + (img + (long)(y0 + s - 4) * p.W) * 512 + ycol : ytrash;
+                const half8 t0 = *reinterpret_cast<const half8 *>(t2row + t2r);
+                const half8 t1 = *reinterpret_cast<const half8 *>(t2row + (t2r ^ 64));
+                half8 xs[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xs[u] = *reinterpret_cast<const half8 *>(xres + (xr ^ (u << 6)));
+                half8 o[2] = {t0, t1};
+#pragma unroll
+                for (int u = 0; u < ((DBG & 4) ? 0 : 2); ++u) {
+                    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][0][0], t0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][1][0], t0, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][0][1], t1, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][1][1], t1, acc1, 0, 0, 0);
+                    if constexpr (PROJ) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][0][KS3 - 2], xs[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][1][KS3 - 2], xs[0], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][0][KS3 - 1], xs[1], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[u][1][KS3 - 1], xs[1], acc1, 0, 0, 0);
+                    }
+                    const float *bl = BI + cq * 64 + u * 32 + g * 8;
+                    floatx4 v0 = acc0 + *reinterpret_cast<const floatx4 *>(bl), v1 = acc1 + *reinterpret_cast<const floatx4 *>(bl + 4);
+                    if constexpr (!PROJ) {
+                        v0 += __builtin_convertvector(__builtin_shufflevector(xs[u], xs[u], 0, 1, 2, 3), floatx4);
+                        v1 += __builtin_convertvector(__builtin_shufflevector(xs[u], xs[u], 4, 5, 6, 7), floatx4);
+                    }
+                    const half4 h0 = __builtin_convertvector(v0, half4), h1 = __builtin_convertvector(v1, half4);
+                    o[u] = __builtin_elementwise_max(__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), half8{0, 0, 0, 0, 0, 0, 0, 0});
+                }
+                if constexpr (!(DBG & 8)) {
+                    bn_gstore<0>(yrow, o[0]);
+                    bn_gstore<64>(yrow, o[1]);
+                } else {
+                    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(yrow));
+                }
+            }
+            if constexpr (STAMP) st_n += 1;
+        }
+        // the next unit's prologue rewrites ring slots 0 .. P-1 and its first steps T1 / T2: every wave must be out of this unit's
+        // last step, and this wave's P trailing requests must have landed (they would overwrite the new rows otherwise)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (STAMP) {
+        const unsigned long t1_ = now();
+        unsigned long r1_;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1_)::"memory");
+        if (lane == 0 && wave < 4) {
+            unsigned long *o = p.stamps + ((long)blockIdx.x * 4 + wave) * 8;
+            o[0] = st_w;             // cycles in the wait + barrier at the head of the steps
+            o[1] = 0;
+            o[2] = 0;
+            o[3] = st_n;             // steps
+            o[4] = t1_ - st_t0;
+            o[5] = r1_ - st_r0;
+        }
+    }
+}
+
 bool bneck_fused_eligible(int cin, int cmid, int cout, int stride, int groups, bool proj, long N, int H, int W, vk_dtype dt) {
     const char *v = getenv("VK_BNECK_FUSED");            // "0" disables (A/B switch and comparison tests; re-read per call)
     if (v && v[0] == '0') return false;
@@ -519,6 +801,113 @@ int launch_bneck_fused(const void *x, int N, int H, int W, int cin, bool proj, c
     VK_REQUIRE(nt > 0 && nt < (1L << 31), VK_EINVAL, "bneck_fused: %ld tiles", nt);
     k.ntiles = (int)nt;
     k.x_last = (unsigned)(((long)N * H * W - 1) * cin * 2);
+    const char *rv = getenv("VK_BNECK_ROWS");            // "0": the tile form (A/B switch and comparison tests; re-read per call)
+    if (!(rv && rv[0] == '0')) {
+        BneckRowsK r;
+        r.x = (const char *)x;
+        r.w1 = (const char *)w1;
+        r.w2 = (const char *)w2;
+        r.w3 = (const char *)w3;
+        r.b1 = b1;
+        r.b2 = b2;
+        r.b3 = b3;
+        r.y = (char *)y;
+        r.trash = trash[dev];
+        r.N = N;
+        r.H = H;
+        r.W = W;
+        r.tw = ceil_div(W, ceil_div(W, 30));
+        r.strips = ceil_div(W, r.tw);
+        // rows per unit: the split of the image height that takes the fewest steps over the rounds of the grid (a unit of ru rows
+        // takes ru + 4 steps and a prologue; at least 16 rows per unit)
+        const int grid_ = n_cu[dev];
+        long best = -1;
+        r.vsplit = 1;
+        for (int vs = 1; vs <= std::max(1, H / 16); ++vs) {
+            const int ru_ = ceil_div(H, vs), vs_ = ceil_div(H, ru_);
+            const long units_ = (long)N * r.strips * vs_;
+            const long cost = ((units_ + grid_ - 1) / grid_) * (ru_ + 8);
+            if (best < 0 || cost < best) {
+                best = cost;
+                r.vsplit = vs_;
+            }
+        }
+        r.ru = ceil_div(H, r.vsplit);
+        r.vsplit = ceil_div(H, r.ru);
+        const long nu = (long)N * r.strips * r.vsplit;
+        VK_REQUIRE(nu > 0 && nu < (1L << 31), VK_EINVAL, "bneck_fused: %ld units", nu);
+        r.nunits = (int)nu;
+        r.stamps = nullptr;
+        static bool rattr[VK_MAX_DEVICES][2] = {};
+        KernelTimer *tmr = g_timer;
+        hipEvent_t f0 = nullptr, f1 = nullptr;
+        if (tmr) {
+            f0 = tmr->get();
+            f1 = tmr->get();
+            VK_CHECK_HIP(hipEventRecord(f0, stream));
+        }
+#ifdef VK_ABLATION
+        if (const char *sf = getenv("VK_BNECK_STAMPS")) {     // diagnostic: one stamped launch, 8 words per wave appended to the file
+            const size_t nb = (size_t)grid_ * 4 * 8 * sizeof(unsigned long);
+            VK_CHECK_HIP(hipMalloc((void **)&r.stamps, nb));
+            VK_CHECK_HIP(hipMemsetAsync(r.stamps, 0, nb, stream));
+            const int dbg = getenv("VK_BNECK_DBG") ? atoi(getenv("VK_BNECK_DBG")) : 0;
+            if (proj) {
+                VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_rows_kernel<64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, br_smem<64>()));
+                hipLaunchKernelGGL((bneck64_rows_kernel<64, true, true>), dim3(grid_), dim3(512), br_smem<64>(), stream, r);
+            } else {
+                switch (dbg) {
+#define VKN_DBG_CASE(D_)                                                                                                                   \
+    case D_:                                                                                                                               \
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_rows_kernel<256, false, true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, br_smem<256>())); \
+        hipLaunchKernelGGL((bneck64_rows_kernel<256, false, true, D_>), dim3(grid_), dim3(512), br_smem<256>(), stream, r);                 \
+        break;
+                    VKN_DBG_CASE(1) VKN_DBG_CASE(2) VKN_DBG_CASE(4) VKN_DBG_CASE(8) VKN_DBG_CASE(16) VKN_DBG_CASE(7) VKN_DBG_CASE(15) VKN_DBG_CASE(31) VKN_DBG_CASE(24) VKN_DBG_CASE(3)
+#undef VKN_DBG_CASE
+                    default:
+                        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_rows_kernel<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, br_smem<256>()));
+                        hipLaunchKernelGGL((bneck64_rows_kernel<256, false, true>), dim3(grid_), dim3(512), br_smem<256>(), stream, r);
+                }
+            }
+            VK_CHECK_HIP(hipStreamSynchronize(stream));
+            std::vector<unsigned long> hst((size_t)grid_ * 4 * 8);
+            VK_CHECK_HIP(hipMemcpy(hst.data(), r.stamps, nb, hipMemcpyDeviceToHost));
+            VK_CHECK_HIP(hipFree(r.stamps));
+            if (FILE *f = fopen(sf, "a")) {
+                fprintf(f, "# rows form: wg wave wait_cycles 0 0 steps kernel_cycles kernel_ticks(10ns)  proj=%d units=%d ru=%d tw=%d\n", (int)proj, r.nunits, r.ru, r.tw);
+                for (int w = 0; w < grid_ * 4; ++w) {
+                    fprintf(f, "%d %d", w / 4, w % 4);
+                    for (int i = 0; i < 6; ++i) fprintf(f, " %lu", hst[(size_t)w * 8 + i]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+            return VK_OK;
+        }
+#endif
+        if (proj) {
+            if (!rattr[dev][1]) {
+                VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_rows_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, br_smem<64>()));
+                rattr[dev][1] = true;
+            }
+            hipLaunchKernelGGL((bneck64_rows_kernel<64, true>), dim3(grid_), dim3(512), br_smem<64>(), stream, r);
+        } else {
+            if (!rattr[dev][0]) {
+                VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bneck64_rows_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, br_smem<256>()));
+                rattr[dev][0] = true;
+            }
+            hipLaunchKernelGGL((bneck64_rows_kernel<256, false>), dim3(grid_), dim3(512), br_smem<256>(), stream, r);
+        }
+        VK_CHECK_HIP(hipGetLastError());
+        if (tmr) {
+            VK_CHECK_HIP(hipEventRecord(f1, stream));
+            const double M = (double)N * H * W;
+            const double fl = 2.0 * M * (64.0 * cin + 64.0 * 576 + 256.0 * (proj ? 128 : 64));
+            tmr->recs.push_back({concurrent ? 6 : 11, fl, f0, f1, (int)M, 256, cin, 3, 1,
+                                 2.0 * (M * cin + M * 256 + 64.0 * cin + 64.0 * 576 + 256.0 * (proj ? 128 : 64))});
+        }
+        return VK_OK;
+    }
     const int grid = n_cu[dev];                   // a multiple of 8: every XCD walks its own range of tiles
     k.stamps = nullptr;
 #ifdef VK_ABLATION
