@@ -290,16 +290,17 @@ def selftest_launch(a):
     return 0
 
 
-def launch_ranks(a):
+def launch_ranks(a, script=None):
     """--gpus N > 1 without a launcher: start the N ranks as children (torch.distributed.run) from this process, which
-    has not imported torch or touched HIP, relay rank 0's one JSON line on stdout and return the job's exit code."""
+    has not imported torch or touched HIP, relay rank 0's one JSON line on stdout and return the job's exit code.
+    `script`: the file the ranks run (default: this one; tools/extract_bench.py passes itself)."""
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script or __file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)

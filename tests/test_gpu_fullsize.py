@@ -134,12 +134,31 @@ def test_full_size_image_fp16_fast_vs_emulating_oracle(bench_model, one_image):
     e_l = G.rel_err(s16, s32)
     print(f"[full size, fp16 vs fp32 oracle, same RoIs] obj_logits rel err {e_l:.3e}")
     assert e_l <= 2e-3
-    # free-running detections, matched by box and class (reported)
+    # free-running detections, matched by box and class; every detection of the fp16 run that the fp32 oracle does not have is
+    # traced to its RoI and printed with its margin: the fp32 oracle's score of the SAME proposal against the oracle's cut (the
+    # lowest score it kept among its max_detections) -- a detection at the cut, or one whose NMS rival sits at the IoU threshold,
+    # flips under any perturbation of the logits, fp16 rounding included
     gb, rb = out["boxes"][0].cpu(), ref["boxes"][0]
-    matched = 0
+    keep16 = m.get_stage("keep_ids").cpu()[0]
+    p32_all, c32_all = torch.softmax(st["obj_logits"], -1)[:, :-1].max(-1)
+    pb32 = st["proposal_boxes"][0]
+    cut = float(ref["obj_probs"][0].min())
+    kept32 = set(int(v) for v in st["keep_ids"][0].tolist())
+    matched, unmatched = 0, []
     for i in range(len(gb)):
         d = (rb - gb[i]).abs().max(dim=1).values
         j = int(d.argmin())
-        matched += int(d[j] <= 1.0 and int(out["obj_ids"][0][i]) == int(ref["obj_ids"][0][j]))
-    print(f"[full size, fp16 vs fp32 oracle, free-running] {matched} of {len(gb)} detections matched by box (1 px) and class")
-    assert matched >= len(gb) // 2
+        if d[j] <= 1.0 and int(out["obj_ids"][0][i]) == int(ref["obj_ids"][0][j]):
+            matched += 1
+            continue
+        r16 = int(keep16[i])
+        dd = (pb32 - pb[0, r16]).abs().max(dim=1).values
+        r32 = int(dd.argmin())
+        unmatched.append((i, r16, r32, float(dd[r32]), float(out["obj_probs"][0][i]), float(p32_all[r32]), int(out["obj_ids"][0][i]),
+                          int(c32_all[r32]), r32 in kept32))
+    print(f"[full size, fp16 vs fp32 oracle, free-running] {matched} of {len(gb)} detections matched by box (1 px) and class; "
+          f"the oracle's cut (lowest kept score) {cut:.4f}")
+    for i, r16, r32, dist, p16, p32, c16, c32, in32 in unmatched:
+        print(f"    detection {i}: RoI {r16} (fp32 RoI {r32}, proposal boxes {dist:.3f} px apart) score fp16 {p16:.4f} / fp32 {p32:.4f}, "
+              f"class {c16} / {c32}, margin to the cut {p32 - cut:+.4f}, {'kept by the oracle too (box or class differs)' if in32 else 'not kept by the oracle'}")
+    assert matched >= len(gb) - 5, unmatched

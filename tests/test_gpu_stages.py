@@ -417,7 +417,10 @@ def test_conv_gemm4_kernel_bit_identical(M_hw, cin, cout, res, relu, monkeypatch
                                                         (70001, 1024, 0, 512, False, False), (33000, 2048, 0, 2048, True, True),
                                                         # res4's conv1 (full and half batch: 525 / 263 tiles), other grids of full rounds + a few tiles
                                                         (67200, 1024, 0, 256, True, False), (134400, 1024, 0, 256, True, False),
-                                                        (66000, 512, 1024, 512, True, False), (66500, 2048, 0, 256, True, True)])
+                                                        (66000, 512, 1024, 512, True, False), (66500, 2048, 0, 256, True, True),
+                                                        # rows beyond the descriptor's 14-bit stride (stride = pitch / 2 or / 4, index = row * 2 or * 4):
+                                                        # the FPN box head's fc1 (12544 -> 1024 at 32 x 1000 RoIs) and a 33 KB row
+                                                        (32000, 12544, 0, 1024, True, False), (2100, 16512, 0, 256, False, False)])
 def test_conv_gemm4_many_tiles_per_workgroup(M, c1, c2, cout, relu, use_res, monkeypatch):
     """conv_gemm4's persistent workgroups at sizes where each walks several tiles (one LDS ring across tile boundaries, the
     next tile's first stages requested by the previous tile's last ones, a ragged last tile): bit-identical to the ring kernel."""

@@ -37,6 +37,7 @@ struct Gemm4K {
     char *y;
     int M;
     int cin_bytes, cin2_bytes;
+    int xmul, x2mul;     // row pitches beyond the descriptor's 14-bit stride: stride = pitch / mul, index = row * mul (1, 2 or 4)
     int st1;             // 32-channel stages of the first input (== stages when x2 is null)
     int stages;          // all stages (even, >= 8)
     int wrow_bytes;
@@ -113,10 +114,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
         asm volatile("" : "+v"(stid));
         const int slrow = (stid & 63) >> 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T.xi[i] = (unsigned)min((wave * 4 + i) * 16 + slrow, p.M - 1 - T.m0);   // rows past M are computed and dropped
-        T.rx1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)T.m0 * p.cin_bytes), (short)p.cin_bytes, 0x7fffffff, 0x00020000);
+        // (the index is shared by both inputs, so a layer with two of them needs xmul == x2mul: the launcher checks)
+        for (int i = 0; i < 4; ++i) T.xi[i] = (unsigned)min((wave * 4 + i) * 16 + slrow, p.M - 1 - T.m0) * (unsigned)p.xmul;   // rows past M are computed and dropped
+        T.rx1 = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long)T.m0 * p.cin_bytes), (short)(p.cin_bytes / p.xmul), 0x7fffffff, 0x00020000);
         T.rx2 = __builtin_amdgcn_make_buffer_rsrc((void *)((p.x2 ? p.x2 : p.x) + (long)T.m0 * p.cin2_bytes),
-                                                  (short)(p.x2 ? p.cin2_bytes : p.cin_bytes), 0x7fffffff, 0x00020000);
+                                                  (short)(p.x2 ? p.cin2_bytes / p.x2mul : p.cin_bytes / p.xmul), 0x7fffffff, 0x00020000);
         T.rw = __builtin_amdgcn_make_buffer_rsrc((void *)(p.w + (long)T.n0 * p.wrow_bytes), 0, 0x7fffffff, 0x00020000);
     };
     const int dma_x0 = (wave * 4) * 1024;                  // byte offset of this wave's first pixel-row piece in a slot
@@ -461,7 +463,9 @@ bool conv_gemm4_eligible(const ConvArgs &a) {
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cout > 8192) return false;      // (the bias rides behind the ring in LDS)
     const int cin2 = a.x2 ? a.Cin2 : 0;
     if (a.Cin % 32 != 0 || cin2 % 32 != 0 || (a.Cin + cin2) % 128 != 0 || a.Cin + cin2 < 1024) return false;   // groups of four 32-channel stages
-    if (a.Cin * 2 >= 16384 || cin2 * 2 >= 16384) return false;         // the row pitch is a 14-bit descriptor stride
+    // the row pitch is a 14-bit descriptor stride; longer rows (the FPN box head's 12544-wide fc1) run with stride = pitch / 2 or / 4
+    // and index = row * 2 or * 4 (one input only: the index is shared)
+    if (cin2 ? (a.Cin * 2 >= 16384 || cin2 * 2 >= 16384) : (a.Cin * 2 >= 4 * 16384 || (a.Cin * 2) % 64 != 0)) return false;
     if ((long)a.Cout * (a.Cin + cin2) * 2 >= (1L << 32)) return false;   // 32-bit weight offsets
     const long M = (long)a.N * a.Ho * a.Wo;
     if (M < 8 * 256 || M >= (1L << 31) - 256) return false;
@@ -492,6 +496,9 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     k.M = (int)M;
     k.cin_bytes = a.Cin * 2;
     k.cin2_bytes = cin2 * 2;
+    k.xmul = k.cin_bytes < 16384 ? 1 : (k.cin_bytes < 2 * 16384 ? 2 : 4);
+    k.x2mul = 1;
+    VK_REQUIRE(k.xmul == 1 || !a.x2, VK_EINVAL, "conv_gemm4: a two-input layer needs rows below 16 KiB");
     k.stages = (a.Cin + cin2) / 32;
     k.st1 = a.x2 ? a.Cin / 32 : k.stages;
     k.wrow_bytes = (a.Cin + cin2) * 2;

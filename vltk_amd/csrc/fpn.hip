@@ -171,6 +171,27 @@ __global__ void upsample2x_add_kernel(const T *__restrict__ lat, const T *__rest
     y[i] = (T)((float)lat[i] + (float)top[((n * Ht + ht) * Wt + wt) * C + c]);
 }
 
+// 16 bytes per lane (8 channels of a 16-bit type) for channel counts that are multiples of 8: the scalar form above moves 2 bytes
+// per lane (P2 of 32 images: 1.7 ms for 2.7 GB; this one runs at the copy rate).  Same arithmetic per element: fp32 add, one rounding.
+template <typename T>
+__global__ void upsample2x_add_vec8_kernel(const T *__restrict__ lat, const T *__restrict__ top, T *__restrict__ y, int H, int W, int Ht, int Wt,
+                                           int C8, long total8) {
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int c = (int)(i % C8);
+    const long px = i / C8;
+    const int w = (int)(px % W), h = (int)((px / W) % H);
+    const long n = px / ((long)W * H);
+    const int ht = min(h >> 1, Ht - 1), wt = min(w >> 1, Wt - 1);
+    const vec8 a = reinterpret_cast<const vec8 *>(lat)[i];
+    const vec8 b = reinterpret_cast<const vec8 *>(top)[((n * Ht + ht) * Wt + wt) * C8 + c];
+    vec8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)((float)a[e] + (float)b[e]);
+    reinterpret_cast<vec8 *>(y)[i] = o;
+}
+
 template <typename T>
 __global__ void subsample2_kernel(const T *__restrict__ x, T *__restrict__ y, int H, int W, int Ho, int Wo, int C, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,6 +271,18 @@ int vk_upsample2x_add(const void *lateral, const void *top, void *y, int N, int 
     VK_REQUIRE(lateral && top && y && N > 0 && H > 0 && W > 0 && C > 0, VK_EINVAL, "upsample2x_add: bad arguments");
     VK_REQUIRE(2 * Ht >= H && 2 * Wt >= W, VK_EINVAL, "upsample2x_add: the %dx%d top map does not cover %dx%d", Ht, Wt, H, W);
     const long total = (long)N * H * W * C;
+    const bool aligned = (((uintptr_t)lateral | (uintptr_t)top | (uintptr_t)y) & 15) == 0;
+    if (C % 8 == 0 && aligned && (dt == VK_F16 || dt == VK_BF16)) {
+        const long total8 = total / 8;
+        if (dt == VK_F16)
+            hipLaunchKernelGGL(upsample2x_add_vec8_kernel<_Float16>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const _Float16 *)lateral, (const _Float16 *)top, (_Float16 *)y, H, W, Ht, Wt, C / 8, total8);
+        else
+            hipLaunchKernelGGL(upsample2x_add_vec8_kernel<__bf16>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const __bf16 *)lateral, (const __bf16 *)top, (__bf16 *)y, H, W, Ht, Wt, C / 8, total8);
+        VK_CHECK_HIP(hipGetLastError());
+        return VK_OK;
+    }
     VK_DT_SWITCH(dt, hipLaunchKernelGGL(upsample2x_add_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                                         (const T *)lateral, (const T *)top, (T *)y, H, W, Ht, Wt, C, total));
     VK_CHECK_HIP(hipGetLastError());

@@ -125,8 +125,30 @@ class _Bottleneck:
                 self.fused = (torch.from_numpy(np.ascontiguousarray(cat).reshape(-1)).to(model.device),
                               torch.from_numpy(c3.host[1] + sc.host[1]).to(model.device))
 
+    def _whole_block_kernel(self, x):
+        """res2's blocks (64 bottleneck channels, 256 out, stride 1, f16) run as ONE kernel: csrc/bneck_fused.hip, as in the C4
+        model (bit-identical to the layer-by-layer kernels; VK_BNECK_FUSED=0 switches it off)."""
+        m, c1, c2, c3 = self.m, self.conv1, self.conv2, self.conv3
+        if m.dt != L.VK_F16 or os.environ.get("VK_BNECK_FUSED") == "0":
+            return False
+        if not (c1.cout == 64 and c3.cout == 256 and c1.stride == 1 and c2.stride == 1 and c2.dil == 1 and c2.groups == 1):
+            return False
+        proj = self.shortcut is not None
+        if (proj and (self.fused is None or c1.cin != 64)) or (not proj and c1.cin != 256):
+            return False
+        N, H, W, _ = x.shape
+        return N * H * W * 512 < (1 << 31)
+
     def __call__(self, x):
         m = self.m
+        if self._whole_block_kernel(x):
+            N, H, W, cin = x.shape
+            proj = self.shortcut is not None
+            w3, b3 = (self.fused if proj else (self.conv3.w, self.conv3.b))
+            y = torch.empty((N, H, W, 256), dtype=m.tdt, device=m.device)
+            L.call("vk_bottleneck64", x.data_ptr(), N, H, W, cin, int(proj), self.conv1.w.data_ptr(), self.conv1.b.data_ptr(),
+                   self.conv2.w.data_ptr(), self.conv2.b.data_ptr(), w3.data_ptr(), b3.data_ptr(), y.data_ptr(), m._stream())
+            return y
         t = self.conv2(self.conv1(x, relu=True), relu=True)
         if self.fused is not None:
             N, H, W, c1 = t.shape
