@@ -608,6 +608,30 @@ def test_roi_pool(dt):
     np.testing.assert_array_equal(G.to_nchw(y, dt).numpy(), ref.numpy())
 
 
+def test_roi_pool_at_real_size():
+    """The f16 RoIPool at the head's real shape (res4 map 50 x 84 x 1024, 14 x 14 bins, 600 RoIs from slivers to the whole image,
+    boxes reaching outside): every output written, a sample of RoIs bit-exact against the oracle."""
+    g = _rng(17)
+    N, Cc, H, W, Pp = 2, 1024, 50, 84, 14
+    x = torch.from_numpy(g.standard_normal((N, Cc, H, W)).astype(np.float32)).half().float()
+    rois = [[0, 0, 0, 1333, 800], [1, -40, -40, 1400, 900], [0, 5, 5, 9, 9], [1, 640, 0, 660, 800], [0, 0, 400, 1333, 410],
+            [1, 1300, 780, 1333, 800], [0, 2000, 2000, 2100, 2100]]
+    for _ in range(593):
+        cx, cy = g.uniform(0, 1333), g.uniform(0, 800)
+        w, h = np.exp(g.uniform(np.log(8), np.log(1200))), np.exp(g.uniform(np.log(8), np.log(800)))
+        rois.append([int(g.integers(0, N)), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2])
+    r = np.asarray(rois, dtype=np.float32)
+    xd = G.to_nhwc(x, L.VK_F16)
+    rd = torch.from_numpy(r).to(G.DEV)
+    y = torch.full((len(r), Pp, Pp, Cc), float("nan"), dtype=torch.float16, device=G.DEV)
+    L.call("vk_roi_pool", G.P(xd), N, H, W, Cc, G.P(rd), len(r), 1.0 / 16, Pp, G.P(y), L.VK_F16, G.stream())
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any()
+    sample = list(range(7)) + list(range(7, 600, 37))
+    ref = orc.roi_pool(x, torch.from_numpy(r[sample]), Pp, 1.0 / 16)
+    np.testing.assert_array_equal(y[sample].float().permute(0, 3, 1, 2).cpu().numpy(), ref.numpy())
+
+
 @pytest.mark.parametrize("dt", [L.VK_F32, L.VK_F16], ids=["fp32", "fp16"])
 def test_mean_pool(dt):
     g = _rng(5)

@@ -18,6 +18,7 @@ import gpu_util as G             # noqa: E402
 SHAPES = {
     "head_conv2": (1024, 14, 14, 512, 512, 3, 1, 2, 2, False),
     "head_conv3": (1024, 14, 14, 512, 2048, 1, 1, 0, 1, True),
+    "head_conv3_full": (9600, 14, 14, 512, 2048, 1, 1, 0, 1, True),
     "head_conv1": (1024, 14, 14, 2048, 512, 1, 1, 0, 1, False),
     "head_short": (1024, 14, 14, 1024, 2048, 1, 1, 0, 1, False),
     "res4_conv3": (32, 50, 84, 256, 1024, 1, 1, 0, 1, True),
@@ -31,6 +32,10 @@ SHAPES = {
 
 def main():
     variants = [v for v in os.environ.get("VARIANTS", "").split(",") if v]   # e.g. VARIANTS=0,4,8: VK_CONV256_DBG values, interleaved rounds
+    # ENVVARIANTS="VK_GEMM4_MINK=512+VK_CONV_WS=0,VK_GEMM4_MINK=1024": arbitrary environment settings per variant, interleaved
+    envvariants = [v for v in os.environ.get("ENVVARIANTS", "").split(",") if v]
+    if envvariants:
+        variants = ["e:" + v for v in envvariants]
     names = sys.argv[1:] or list(SHAPES)
     iters = int(os.environ.get("ITERS", "10"))
     g = np.random.Generator(np.random.PCG64(0))
@@ -53,11 +58,19 @@ def main():
             for rnd in range(int(os.environ.get("ROUNDS", "5"))):
                 for vkey in variants:
                     v = vkey
+                    if v.startswith("e:"):
+                        for ev in envvariants:                         # clear what the other variants set
+                            for kv in ev.split("+"):
+                                os.environ.pop(kv.split("=")[0], None)
+                        for kv in v[2:].split("+"):
+                            os.environ[kv.split("=")[0]] = kv.split("=")[1]
+                        v = "0"
                     # a variant is "<dbg>" or "<kernel><dbg>", e.g. "0", "a0", "p0", "d0"
                     # "p..." = LDS-panel 3x3 kernel enabled, otherwise the im2col ring kernels
-                    os.environ["VK_CONV3X3_PANEL"] = "1" if v[0] == "p" else "0"
-                    os.environ["VK_CONV_DUO"] = "1" if v[0] == "d" else "0"
-                    os.environ["VK_CONV256_DBG"] = v.lstrip("apd") or "0"
+                    if not vkey.startswith("e:"):
+                        os.environ["VK_CONV3X3_PANEL"] = "1" if v[0] == "p" else "0"
+                        os.environ["VK_CONV_DUO"] = "1" if v[0] == "d" else "0"
+                        os.environ["VK_CONV256_DBG"] = v.lstrip("apd") or "0"
                     run()
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

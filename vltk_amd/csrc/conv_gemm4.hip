@@ -462,7 +462,9 @@ bool conv_gemm4_eligible(const ConvArgs &a) {
     if (a.kh != 1 || a.kw != 1 || a.pad != 0 || a.stride != 1) return false;
     if (a.Cout % 256 != 0 || a.ldy != a.Cout || a.Cout > 8192) return false;      // (the bias rides behind the ring in LDS)
     const int cin2 = a.x2 ? a.Cin2 : 0;
-    if (a.Cin % 32 != 0 || cin2 % 32 != 0 || (a.Cin + cin2) % 128 != 0 || a.Cin + cin2 < 1024) return false;   // groups of four 32-channel stages
+    int min_k = 1024;
+    if (const char *mk = getenv("VK_GEMM4_MINK")) min_k = atoi(mk) >= 256 ? atoi(mk) : 1024;     // A/B switch (tools/conv_bench.py)
+    if (a.Cin % 32 != 0 || cin2 % 32 != 0 || (a.Cin + cin2) % 128 != 0 || a.Cin + cin2 < min_k) return false;   // groups of four 32-channel stages
     // the row pitch is a 14-bit descriptor stride; longer rows (the FPN box head's 12544-wide fc1) run with stride = pitch / 2 or / 4
     // and index = row * 2 or * 4 (one input only: the index is shared)
     if (cin2 ? (a.Cin * 2 >= 16384 || cin2 * 2 >= 16384) : (a.Cin * 2 >= 4 * 16384 || (a.Cin * 2) % 64 != 0)) return false;
