@@ -128,11 +128,12 @@ def test_full_size_image_fp16_fast_vs_emulating_oracle(bench_model, one_image):
     feat16 = m.get_stage("feature_pooled").cpu()[:int(pc[0])]
     e = G.rel_err(feat16, feat32)
     print(f"[full size, fp16 vs fp32 oracle, same {int(pc[0])} RoIs] feature_pooled rel err {e:.3e}")
-    assert e <= 2e-3
+    assert e <= 1e-3          # north_star's bound on what the path hands over (5.8e-4 measured)
     s32, a32, _ = o32.predictor(feat32)
     s16 = m.get_stage("obj_logits").cpu()[:int(pc[0]), :s32.shape[1]]
     e_l = G.rel_err(s16, s32)
     print(f"[full size, fp16 vs fp32 oracle, same RoIs] obj_logits rel err {e_l:.3e}")
+    # 1.3e-3 measured; DESIGN.md 5a: no stage carries it (f16 weights alone: 1.07e-3, f16 storage alone: 1.22e-3 at this size)
     assert e_l <= 2e-3
     # free-running detections, matched by box and class; every detection of the fp16 run that the fp32 oracle does not have is
     # traced to its RoI and printed with its margin: the fp32 oracle's score of the SAME proposal against the oracle's cut (the
