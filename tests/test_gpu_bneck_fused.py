@@ -143,6 +143,26 @@ def test_bottleneck64_many_tiles_reproducible(form, monkeypatch):
     assert torch.equal(y1, run_layers(x, p, False))
 
 
+def test_bottleneck64_beyond_two_gigabytes():
+    """Batch 64 of the real res2 map: 2.18 GB of x and of y -- byte offsets beyond 2^31 (the row form keeps them unsigned / 64-bit);
+    the last image against the layer-by-layer kernels on a batch of its own."""
+    N, H, W = 64, 200, 333
+    g = torch.Generator(device=G.DEV).manual_seed(7)
+    xd = torch.randn((N, H, W, 256), generator=g, device=G.DEV, dtype=torch.float16).relu_()
+    p = make_block(5, 256, False)
+    w1d, b1d, w2d, b2d, w3d, b3d = packed(p, False)
+    y = torch.full((N, H, W, 256), float("nan"), dtype=torch.float16, device=G.DEV)
+    L.call("vk_bottleneck64", G.P(xd), N, H, W, 256, 0, G.P(w1d), G.P(b1d), G.P(w2d), G.P(b2d), G.P(w3d), G.P(b3d), G.P(y), G.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(y[-1].float()).all() and torch.isfinite(y[0].float()).all()
+    for n in (0, 40, 63):                                  # images below, across and above the 2^31-byte mark
+        y1 = torch.empty((1, H, W, 256), dtype=torch.float16, device=G.DEV)
+        x1 = xd[n:n + 1].contiguous()
+        L.call("vk_bottleneck64", G.P(x1), 1, H, W, 256, 0, G.P(w1d), G.P(b1d), G.P(w2d), G.P(b2d), G.P(w3d), G.P(b3d), G.P(y1), G.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(y[n:n + 1], y1), n
+
+
 def test_model_with_and_without_the_fused_block(monkeypatch):
     """The whole forward with res2 on the fused kernel (default) and on the layer-by-layer kernels (VK_BNECK_FUSED=0):
     identical outputs and res4."""

@@ -762,7 +762,10 @@ bool bneck_fused_eligible(int cin, int cmid, int cout, int stride, int groups, b
     if (v && v[0] == '0') return false;
     if (dt != VK_F16 || cmid != 64 || cout != 256 || stride != 1 || groups != 1) return false;
     if (!((cin == 256 && !proj) || (cin == 64 && proj))) return false;
-    if (H < 1 || W < 1 || N * H * W * 512 >= (1L << 31)) return false;       // 32-bit byte offsets into x and y
+    // byte offsets into x: unsigned 32-bit in the row form (64 images of 800 x 1333 are 2.2 GB of res2 map), signed in the tile form
+    const char *rv = getenv("VK_BNECK_ROWS");
+    const long lim = (rv && rv[0] == '0') ? (1L << 31) : (1L << 32) - (1L << 20);
+    if (H < 1 || W < 1 || N * H * W * 512 >= lim) return false;
     return true;
 }
 
@@ -908,6 +911,7 @@ int launch_bneck_fused(const void *x, int N, int H, int W, int cin, bool proj, c
         }
         return VK_OK;
     }
+    VK_REQUIRE((long)N * H * W * 512 < (1L << 31), VK_EINVAL, "bneck_fused: the tile form keeps signed 32-bit byte offsets");
     const int grid = n_cu[dev];                   // a multiple of 8: every XCD walks its own range of tiles
     k.stamps = nullptr;
 #ifdef VK_ABLATION

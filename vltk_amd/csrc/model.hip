@@ -712,7 +712,9 @@ int vk_bottleneck64(const void *x, int N, int H, int W, int cin, int proj, const
                     const float *b2, const void *w3, const float *b3, void *y, void *stream) {
     VK_REQUIRE(x && w1 && b1 && w2 && b2 && w3 && b3 && y && N > 0 && H > 0 && W > 0, VK_EINVAL, "bottleneck64: bad arguments");
     VK_REQUIRE((cin == 256 && !proj) || (cin == 64 && proj), VK_EINVAL, "bottleneck64: cin must be 256 (identity) or 64 (projection)");
-    VK_REQUIRE((long)N * H * W * 512 < (1L << 31), VK_EINVAL, "bottleneck64: tensor beyond the 32-bit byte offsets");
+    VK_REQUIRE(bneck_fused_eligible(cin, 64, 256, 1, 1, proj != 0, N, H, W, VK_F16) || getenv("VK_BNECK_FUSED"), VK_EINVAL,
+               "bottleneck64: tensor beyond the 32-bit byte offsets");
+    VK_REQUIRE((long)N * H * W * 512 < (1L << 32) - (1L << 20), VK_EINVAL, "bottleneck64: tensor beyond the 32-bit byte offsets");
     return launch_bneck_fused(x, N, H, W, cin, proj != 0, w1, b1, w2, b2, w3, b3, y, false, (hipStream_t)stream);
 }
 
