@@ -11,7 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvltk_hip.so")
 # tools only: the ablation build (make ABLATION=1 OUT=.../libvltk_hip_ablation.so) -- stamp / timing-only kernels, never the product
-if os.environ.get("VLTK_AMD_ABLATION_LIB") == "1":
+if os.environ.get("VLTK_AMD_LIB"):              # tools only: A/B of two builds on one box (e.g. the previous commit's library)
+    LIB_PATH = os.environ["VLTK_AMD_LIB"]
+elif os.environ.get("VLTK_AMD_ABLATION_LIB") == "1":
     LIB_PATH = LIB_PATH.replace("libvltk_hip.so", "libvltk_hip_ablation.so")
 
 VK_OK, VK_EINVAL, VK_ENOTIMPL, VK_ENONFINITE, VK_EWEIGHTS, VK_EHIP, VK_ENOMEM = range(7)
