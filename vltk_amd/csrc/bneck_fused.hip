@@ -502,7 +502,10 @@ struct BneckRowsK {
     unsigned long *stamps;
 };
 
-constexpr int BR_P = 3;                          // x rows in flight ahead of the row being multiplied
+#ifndef VK_BR_P
+#define VK_BR_P 3
+#endif
+constexpr int BR_P = VK_BR_P;                    // x rows in flight ahead of the row being multiplied
 constexpr int BR_R = BR_P + 4;                   // x-row ring: row s is last read (residual) at step s + 3
 constexpr int BR_T1_ROW = 32 * 128, BR_T1_BYTES = 4 * BR_T1_ROW + 256, BR_T2_BYTES = 2 * 32 * 128;
 template <int CIN>
@@ -635,16 +638,22 @@ __global__ __launch_bounds__(512, 2) void bneck64_rows_kernel(BneckRowsK p) {
             // row s's pieces: younger are the 2 stores of step s - P and the pieces + stores of steps s - P + 1 .. s - 1; in the first
             // P steps of a unit: the rest of the prologue's rows and the pieces + stores of the steps so far.  (PROJ: waves 4 - 7
             // request nothing and wait for nothing; the barrier publishes the others' rows.)
-            static_assert(BR_P == 3, "the first-step counts below are written for P = 3");
+            static_assert(BR_P >= 2 && BR_P <= 5, "the first-step counts below cover P = 2 .. 5");
             if (dma_wave && !(DBG & 24)) {
+                // first steps: (P - 1 - s) prologue rows + s x (pieces + stores); a negative template argument is never instantiated
                 if (s >= BR_P)
                     bn_vm_wait<2 + (BR_P - 1) * (NQ + 2)>();
                 else if (s == 0)
                     bn_vm_wait<(BR_P - 1) * NQ>();
                 else if (s == 1)
                     bn_vm_wait<(BR_P - 2) * NQ + (NQ + 2)>();
-                else
-                    bn_vm_wait<(BR_P - 3) * NQ + 2 * (NQ + 2)>();
+                else if (s == 2) {
+                    if constexpr (BR_P > 2) bn_vm_wait<(BR_P > 2 ? BR_P - 3 : 0) * NQ + 2 * (NQ + 2)>();
+                } else if (s == 3) {
+                    if constexpr (BR_P > 3) bn_vm_wait<(BR_P > 3 ? BR_P - 4 : 0) * NQ + 3 * (NQ + 2)>();
+                } else {
+                    if constexpr (BR_P > 4) bn_vm_wait<4 * (NQ + 2)>();
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
