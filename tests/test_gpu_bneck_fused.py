@@ -163,13 +163,25 @@ def test_bottleneck64_beyond_two_gigabytes():
         assert torch.equal(y[n:n + 1], y1), n
 
 
-def test_model_with_and_without_the_fused_block(monkeypatch):
+@pytest.mark.parametrize("case", ["three_ragged", "one_small", "two_full_size"])
+def test_model_with_and_without_the_fused_block(case, monkeypatch):
     """The whole forward with res2 on the fused kernel (default) and on the layer-by-layer kernels (VK_BNECK_FUSED=0):
-    identical outputs and res4."""
-    cfg = vg_c4_config(depth=50, post_nms_topk=40, detections=10)
-    sd = make_state_dict(cfg, seed=31)
-    x = torch.from_numpy(synthetic_images(3, 131, 203, seed=11))
-    shapes = torch.tensor([[131, 203], [97, 180], [120, 161]])
+    identical outputs and res4 -- a ragged batch, a single small image, and two images at the bench's size (800 x 1333, ResNet-101)."""
+    if case == "two_full_size":
+        cfg = vg_c4_config(post_nms_topk=300, detections=100)
+        sd = make_state_dict(cfg, seed=1234)
+        x = torch.from_numpy(synthetic_images(2, 800, 1333, seed=0xF2C))
+        shapes = torch.tensor([[800, 1333], [800, 1333]])
+    elif case == "one_small":
+        cfg = vg_c4_config(depth=50, post_nms_topk=40, detections=10)
+        sd = make_state_dict(cfg, seed=31)
+        x = torch.from_numpy(synthetic_images(1, 64, 96, seed=11))
+        shapes = torch.tensor([[64, 96]])
+    else:
+        cfg = vg_c4_config(depth=50, post_nms_topk=40, detections=10)
+        sd = make_state_dict(cfg, seed=31)
+        x = torch.from_numpy(synthetic_images(3, 131, 203, seed=11))
+        shapes = torch.tensor([[131, 203], [97, 180], [120, 161]])
     m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
     m(x, shapes)
     a = {k: v.clone() for k, v in m.forward_padded().items()}
