@@ -17,10 +17,13 @@ import gpu_util as G             # noqa: E402
 # name: (N, H, W, cin, cout, k, stride, pad, dil, residual)
 SHAPES = {
     "head_conv2": (1024, 14, 14, 512, 512, 3, 1, 2, 2, False),
+    "head_conv2_full": (9600, 14, 14, 512, 512, 3, 1, 2, 2, False),
     "head_conv3": (1024, 14, 14, 512, 2048, 1, 1, 0, 1, True),
     "head_conv3_full": (9600, 14, 14, 512, 2048, 1, 1, 0, 1, True),
     "head_conv1": (1024, 14, 14, 2048, 512, 1, 1, 0, 1, False),
+    "head_conv1_full": (9600, 14, 14, 2048, 512, 1, 1, 0, 1, False),
     "head_short": (1024, 14, 14, 1024, 2048, 1, 1, 0, 1, False),
+    "head_short_full": (9600, 14, 14, 1024, 2048, 1, 1, 0, 1, False),
     "res4_conv3": (32, 50, 84, 256, 1024, 1, 1, 0, 1, True),
     "res4_conv2": (32, 50, 84, 256, 256, 3, 1, 1, 1, False),
     "res4_conv1": (32, 50, 84, 1024, 256, 1, 1, 0, 1, False),

@@ -373,30 +373,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     if constexpr (!(DBG & 8)) {
         auto epilogue = [&](auto res_c, auto relu_c, auto full_c) {
             constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+            // row tile outer, channel half inner: the two 64-byte halves of a pixel's 128-byte line (this wave's 64 channels) leave in
+            // consecutive instructions (round 3; they used to be nine stores apart)
+            const int ch0 = n0 + wc * 64 + g * 8;
+            floatx4 bq[2][2];
 #pragma unroll
             for (int qn = 0; qn < 2; ++qn) {
-                const int ch = n0 + wc * 64 + qn * 32 + g * 8;
-                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(p.bias + ch), b1 = *reinterpret_cast<const floatx4 *>(p.bias + ch + 4);
-                half8 rr[MI];
-                if constexpr (RES) {
+                bq[qn][0] = *reinterpret_cast<const floatx4 *>(p.bias + ch0 + qn * 32);
+                bq[qn][1] = *reinterpret_cast<const floatx4 *>(p.bias + ch0 + qn * 32 + 4);
+            }
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const long m = min(m0 + wr * (MI * 16) + mi * 16 + j, p.M - 1);
-                        rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
-                    }
+            for (int mi = 0; mi < MI; ++mi) {
+                const long m = m0 + wr * (MI * 16) + mi * 16 + j;
+                half8 rr[2];
+                if constexpr (RES) {
+                    const long mr = min(m, (long)p.M - 1);
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn) rr[qn] = *reinterpret_cast<const half8 *>(p.res + (mr * p.ldy + ch0 + qn * 32) * 2);
                 }
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
+                for (int qn = 0; qn < 2; ++qn) {
+                    floatx4 x0 = acc[mi][2 * qn] + bq[qn][0], x1 = acc[mi][2 * qn + 1] + bq[qn][1];
                     if constexpr (RES) {
-                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
-                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 4, 5, 6, 7), floatx4);
+                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[qn], rr[qn], 0, 1, 2, 3), floatx4);
+                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[qn], rr[qn], 4, 5, 6, 7), floatx4);
                     }
                     half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
                     half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                     if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    const long m = m0 + wr * (MI * 16) + mi * 16 + j;
-                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
+                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch0 + qn * 32) * 2) = o;
                 }
             }
         };

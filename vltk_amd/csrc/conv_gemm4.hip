@@ -385,30 +385,35 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
         const int em0 = A.m0, en0 = A.n0;
         auto epilogue = [&](auto res_c, auto relu_c, auto full_c) {
             constexpr bool RES = decltype(res_c)::value, RELU = decltype(relu_c)::value, FULL = decltype(full_c)::value;
+            // pixel-row tile outer, 32-channel group inner: a pixel's 256 bytes (this wave's 128 channels, two 128-byte lines) leave
+            // in four consecutive stores.  (Group outer put the halves of a line 8 stores apart: WRITE_SIZE 1.08-1.13 x the output.)
+            const int ch0 = en0 + wc * 128 + eg * 8;
+            floatx4 bq[4][2];
 #pragma unroll
             for (int qn = 0; qn < 4; ++qn) {
-                const int ch = en0 + wc * 128 + qn * 32 + eg * 8;
-                const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bias_lds + ch), b1 = *reinterpret_cast<const floatx4 *>(bias_lds + ch + 4);
-                half8 rr[8];
-                if constexpr (RES) {          // (these loads retire in order behind the next tile's requests: a layer with a residual waits for them)
+                bq[qn][0] = *reinterpret_cast<const floatx4 *>(bias_lds + ch0 + qn * 32);
+                bq[qn][1] = *reinterpret_cast<const floatx4 *>(bias_lds + ch0 + qn * 32 + 4);
+            }
 #pragma unroll
-                    for (int mi = 0; mi < 8; ++mi) {
-                        const long m = min(em0 + wr * 128 + mi * 16 + ej, p.M - 1);
-                        rr[mi] = *reinterpret_cast<const half8 *>(p.res + (m * p.ldy + ch) * 2);
-                    }
+            for (int mi = 0; mi < 8; ++mi) {
+                const long m = em0 + wr * 128 + mi * 16 + ej;
+                half8 rr[4];
+                if constexpr (RES) {          // (these loads retire in order behind the next tile's requests: a layer with a residual waits for them)
+                    const long mr = min(m, (long)p.M - 1);
+#pragma unroll
+                    for (int qn = 0; qn < 4; ++qn) rr[qn] = *reinterpret_cast<const half8 *>(p.res + (mr * p.ldy + ch0 + qn * 32) * 2);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    floatx4 x0 = acc[mi][2 * qn] + b0, x1 = acc[mi][2 * qn + 1] + b1;
+                for (int qn = 0; qn < 4; ++qn) {
+                    floatx4 x0 = acc[mi][2 * qn] + bq[qn][0], x1 = acc[mi][2 * qn + 1] + bq[qn][1];
                     if constexpr (RES) {
-                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 0, 1, 2, 3), floatx4);
-                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[mi], rr[mi], 4, 5, 6, 7), floatx4);
+                        x0 += __builtin_convertvector(__builtin_shufflevector(rr[qn], rr[qn], 0, 1, 2, 3), floatx4);
+                        x1 += __builtin_convertvector(__builtin_shufflevector(rr[qn], rr[qn], 4, 5, 6, 7), floatx4);
                     }
                     half4 h0 = __builtin_convertvector(x0, half4), h1 = __builtin_convertvector(x1, half4);
                     half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                     if constexpr (RELU) o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-                    const long m = em0 + wr * 128 + mi * 16 + ej;
-                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch) * 2) = o;
+                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + ch0 + qn * 32) * 2) = o;
                 }
             }
         };
