@@ -82,6 +82,23 @@ def test_roi_align_single_level(dt, td, tol, sr, aligned):
     assert G.rel_err(nchw(out), ref) <= tol
 
 
+@pytest.mark.parametrize("P,sr", [(2, 0), (3, 0), (2, 3), (14, 0)])
+def test_roi_align_footprints_beyond_the_weight_tables(P, sr):
+    """The separable kernel keeps per-axis weight tables of 12 rows: bins of 15+ pixels under adaptive sampling, a fixed
+    sampling_ratio over bins much larger than it (gaps between the samples) and inverted boxes take its per-sample loop;
+    P = 14 runs two passes of the bin loop.  All against the oracle, fp32."""
+    gen = np.random.Generator(np.random.PCG64(100 + P * 7 + sr))
+    N, Cc, H, W = 2, 16, 40, 52
+    x = torch.from_numpy(gen.standard_normal((N, Cc, H, W)).astype(np.float32))
+    rois = _rois(gen, 48, N, W * 4, H * 4)
+    rois[3, 1:] = [5, 6, W * 4 - 3, H * 4 - 2]            # the whole map in P x P bins
+    rois[4, 1:] = [90, 80, 40, 20]                        # inverted
+    pool = MultiLevelRoIAlign(P, [1 / 4], sr, True, precision="fp32")
+    out, _ = pool([nhwc(x)], torch.from_numpy(rois))
+    ref = fo.roi_align(x, rois, P, 1 / 4, sr, True)
+    assert G.rel_err(nchw(out), ref) <= 1e-5
+
+
 def test_roi_align_pyramid_routes_by_level():
     gen = np.random.Generator(np.random.PCG64(11))
     N, Cc = 2, 256

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     constexpr int HALO = (PROWS - TILE) / 2;      // 64 or 128 (MI = 9: 48 or 112)
     constexpr int PBYTES = PROWS * 64;
     constexpr int WBASE = 2 * PBYTES;
+    // PP = 3 leaves 16 KiB of the CU's LDS unused: 64 bytes of zeros behind the weight ring.  A fragment read of a pixel whose tap
+    // falls outside the image is pointed there (two VALU instructions per read: a sign-extended bit-field and a bit-select
+    // of the address) instead of zeroing the fragment afterwards (four v_cndmask per read and a compare): round 3, see DESIGN.md 6b.
+    constexpr bool ZROW = PP == 3;
+    constexpr int ZOFF = WBASE + P_NW * P_WSLOT;
 
     const int bid = blockIdx.x, nwg = gridDim.x;
     unsigned long st_k0 = 0;
@@ -113,28 +118,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, j = lane & 15;
 
-    // ---- per-lane tap validity of its MI fragment pixels (rows wr*MI*16 + mi*16 + j): bit ((tap % 3) * 9 + mi) of word tap / 3 ----
-    unsigned vm0 = 0, vm1 = 0, vm2 = 0;           // taps 0-2 | 3-5 | 6-8
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wr * (MI * 16) + mi * 16 + j;
-        if (m < p.M) {
-            const int n_img = m / p.HW;
-            const int rem = m - n_img * p.HW;
-            const int ho = rem / p.W, wo = rem - ho * p.W;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int hi = ho + (tap / 3 - 1) * p.dil, wi = wo + (tap % 3 - 1) * p.dil;
-                const unsigned ok = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? 1u : 0u;
-                if (tap < 3)
-                    vm0 |= ok << (tap * 9 + mi);
-                else if (tap < 6)
-                    vm1 |= ok << ((tap - 3) * 9 + mi);
-                else
-                    vm2 |= ok << ((tap - 6) * 9 + mi);
-            }
-        }
-    }
+    unsigned vm0 = 0, vm1 = 0, vm2 = 0;           // per-lane tap validity, taps 0-2 | 3-5 | 6-8: filled behind the prologue's requests
 
     // ---- LDS-DMA source state ----
     const int lrow = lane >> 2;
@@ -161,6 +145,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
 
     // ---- fragment addressing ----
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char *)smem;
+    [[maybe_unused]] const unsigned zrow = lds0 + ZOFF;
+    if constexpr (ZROW) {                         // (complete before the prologue's barrier, ahead of the first fragment read)
+        if (tid < 16) *reinterpret_cast<unsigned *>(smem + ZOFF + tid * 4) = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     unsigned w_a[2];
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -185,13 +174,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     const int CS = p.cstages;
 
 #define VKP_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+    // fragment read of row tile MI_ of tap J_ (TW: the lane's validity word of taps 3*(J_/3)..+2, unshifted).  Written as asm: left to
+    // hipcc the select becomes and + compare + s_nop + cndmask.
+#define VKP_DSRX(dst, addr, OFF, TW, J_, MI_)                                                        \
+    do {                                                                                             \
+        if constexpr (ZROW && !(DBG & 1)) {                                                          \
+            unsigned m_, ad_;                                                                        \
+            const unsigned zc_ = zrow - (OFF);                                                       \
+            asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"(TW), "n"(((J_) % 3) * 9 + (MI_))); \
+            asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(ad_) : "v"(m_), "v"(addr), "s"(zc_));    \
+            VKP_DSR(dst, ad_, OFF);                                                                  \
+        } else                                                                                       \
+            VKP_DSR(dst, addr, OFF);                                                                 \
+    } while (0)
 #define VKP_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg))
 #define VKP_WAIT4(reg) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(reg))
 #define VKP_SB() __builtin_amdgcn_sched_barrier(0)
     // zero a fragment whose pixel is outside the image for this tap (4 v_cndmask), then 4 MFMAs
 #define VKP_MMA_ROW(MI, XR, WF, TM)                                                                  \
     do {                                                                                             \
-        if constexpr (!(DBG & 1)) {                                                                  \
+        if constexpr (!(DBG & 1) && !ZROW) {                                                         \
             uintx4 u_ = __builtin_bit_cast(uintx4, XR);                                              \
             const bool v_ = ((TM) >> (MI)) & 1u;                                                     \
             u_[0] = v_ ? u_[0] : 0u;                                                                 \
@@ -235,23 +237,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         asm volatile("" : "+v"(tw));
         return tw >> ((J % 3) * 9);
     };
+    auto tap_word = [&](auto j_c) -> unsigned {       // the unshifted word (VKP_DSRX extracts its bit itself)
+        constexpr int J = decltype(j_c)::value;
+        unsigned tw = J < 3 ? vm0 : (J < 6 ? vm1 : vm2);
+        asm volatile("" : "+v"(tw));
+        return tw;
+    };
     auto pre = [&](auto last_c, auto odd_c, auto j_c, unsigned xa, unsigned &xa_next, const half8 (&wcur)[4]) {
         constexpr bool LAST = decltype(last_c)::value;
         constexpr int ODD = decltype(odd_c)::value;
         constexpr int J = decltype(j_c)::value;
-        const unsigned tm = tap_mask(j_c);
+        const unsigned tm = ZROW ? 0u : tap_mask(j_c);
+        [[maybe_unused]] const unsigned tw = ZROW ? tap_word(j_c) : 0u;
         constexpr bool has_next = !(LAST && J == 8);
         // address of the next step's fragments (next tap; next stage's panel after tap 8)
         if constexpr (has_next) xa_next = (J == 8) ? x_addr_of(1 - ODD, 0) : x_addr_of(ODD, J + 1);
-        VKP_DSR(xw[3], xa, 3072); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(0, xw[0], wcur, tm); VKP_SB();
-        VKP_DSR(xw[0], xa, 4096); VKP_WAIT3(xw[1]); VKP_SB(); VKP_MMA_ROW(1, xw[1], wcur, tm); VKP_SB();
-        VKP_DSR(xw[1], xa, 5120); VKP_WAIT3(xw[2]); VKP_SB(); VKP_MMA_ROW(2, xw[2], wcur, tm); VKP_SB();
-        VKP_DSR(xw[2], xa, 6144); VKP_WAIT3(xw[3]); VKP_SB(); VKP_MMA_ROW(3, xw[3], wcur, tm); VKP_SB();
+        VKP_DSRX(xw[3], xa, 3072, tw, J, 3); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(0, xw[0], wcur, tm); VKP_SB();
+        VKP_DSRX(xw[0], xa, 4096, tw, J, 4); VKP_WAIT3(xw[1]); VKP_SB(); VKP_MMA_ROW(1, xw[1], wcur, tm); VKP_SB();
+        VKP_DSRX(xw[1], xa, 5120, tw, J, 5); VKP_WAIT3(xw[2]); VKP_SB(); VKP_MMA_ROW(2, xw[2], wcur, tm); VKP_SB();
+        VKP_DSRX(xw[2], xa, 6144, tw, J, 6); VKP_WAIT3(xw[3]); VKP_SB(); VKP_MMA_ROW(3, xw[3], wcur, tm); VKP_SB();
         if constexpr (MI == 9) {
-            VKP_DSR(xw[3], xa, 7168); VKP_DSR(xw[4], xa, 8192); VKP_WAIT4(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+            VKP_DSRX(xw[3], xa, 7168, tw, J, 7); VKP_DSRX(xw[4], xa, 8192, tw, J, 8); VKP_WAIT4(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(xw[MI == 9 ? 4 : 3])::"memory");
         } else {
-            VKP_DSR(xw[3], xa, 7168); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
+            VKP_DSRX(xw[3], xa, 7168, tw, J, 7); VKP_WAIT3(xw[0]); VKP_SB(); VKP_MMA_ROW(4, xw[0], wcur, tm); VKP_SB();
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3])::"memory");
         }
         VKP_SB();
@@ -261,7 +270,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
             // the other panel buffer is free once the stage ends.
             constexpr int OUT = LAST ? last_w_in_window<J>() : 2 * (P_NW - 2) + panel_in_window<J, PP>();
             vm_wait<OUT>();
-            asm volatile("s_barrier" ::: "memory");
+            // (DBG 16 / 32, timing only, WRONG results: the barrier on every third tap only / never -- what the per-step barrier costs)
+            if constexpr (!(DBG & 48) || ((DBG & 16) && J % 3 == 2)) asm volatile("s_barrier" ::: "memory");
         }
         VKP_SB();
     };
@@ -271,23 +281,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         constexpr int J = decltype(j_c)::value;
         static_assert(!(LAST && J == 8), "the final step has no POST");
         constexpr int SLOT = (3 * ODD + J) % P_NW;            // == t % 6; also the slot of step t + 6
-        const unsigned tm = tap_mask(j_c);
+        const unsigned tm = ZROW ? 0u : tap_mask(j_c);
+        constexpr int JN = (J + 1) % 9;                   // the next step's tap (tap 0 of the next stage after tap 8)
+        [[maybe_unused]] const unsigned twn = ZROW ? tap_word(std::integral_constant<int, JN>{}) : 0u;
         constexpr bool issue_w = !LAST || (J + P_NW < 9);
         constexpr bool issue_p = !LAST && (J < PP);
         constexpr unsigned so = (unsigned)((SLOT + 1) % P_NW) * P_WSLOT;
         VKP_READ_W(wnext, so);
-        VKP_DSR(xw[0], xa_next, 0);
+        VKP_DSRX(xw[0], xa_next, 0, twn, JN, 0);
         VKP_SB();
         VKP_MMA_ROW(5, xw[1], wcur, tm);
         VKP_SB();
         if constexpr (issue_p) req_panel(cs + 1, J);
         if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 0);
-        VKP_DSR(xw[1], xa_next, 1024);
+        VKP_DSRX(xw[1], xa_next, 1024, twn, JN, 1);
         VKP_SB();
         VKP_MMA_ROW(6, xw[2], wcur, tm);
         VKP_SB();
         if constexpr (issue_w) req_w(SLOT, cs + (J + P_NW) / 9, (J + P_NW) % 9, 1);
-        VKP_DSR(xw[2], xa_next, 2048);
+        VKP_DSRX(xw[2], xa_next, 2048, twn, JN, 2);
         VKP_SB();
         VKP_MMA_ROW(7, xw[3], wcur, tm);
         VKP_SB();
@@ -320,15 +332,72 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         req_w(st, 0, st, 0);
         req_w(st, 0, st, 1);
     }
+    // ---- per-lane tap validity of its MI fragment pixels (rows wr*MI*16 + mi*16 + j): bit ((tap % 3) * 9 + mi) of word tap / 3 ----
+    // Computed HERE, behind the prologue's requests, so that it runs under their HBM latency; and without per-pixel integer
+    // division (round 3: the first form, two divisions and 81 tap tests per lane ahead of the requests, was ~1300 VALU
+    // instructions per wave = 4.7 us of a 133 us workgroup on Res5 conv2).  The wave's first row is placed in its image by
+    // two uniform divisions; a lane's row is at most MI*16 - 1 pixels further: column by a float reciprocal with an exact
+    // +-1 correction (operands < 2^24), at most one image wrap when the image has >= MI*16 pixels.  Tap validity is separable:
+    // three row tests, three column tests.  Images smaller than a wave's rows keep the division form.
+    if (p.HW >= MI * 16 + p.W) {
+        const int mbase = m0 + wr * (MI * 16);
+        const int rem0 = mbase % p.HW, ho0 = rem0 / p.W, wo0 = rem0 - ho0 * p.W;
+        const float rcpw = 1.0f / (float)p.W;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int xcol = wo0 + mi * 16 + j;
+            int q = (int)((float)xcol * rcpw), wo = xcol - q * p.W;
+            if (wo >= p.W) {
+                wo -= p.W;
+                ++q;
+            }
+            if (wo < 0) {
+                wo += p.W;
+                --q;
+            }
+            int ho = ho0 + q;
+            if (ho >= p.H) ho -= p.H;
+            const unsigned c0 = (unsigned)(wo - p.dil) < (unsigned)p.W, c1 = 1u, c2 = (unsigned)(wo + p.dil) < (unsigned)p.W;
+            const unsigned cw = mbase + mi * 16 + j < p.M ? (c0 << mi) | (c1 << (9 + mi)) | (c2 << (18 + mi)) : 0u;
+            vm0 |= (unsigned)(ho - p.dil) < (unsigned)p.H ? cw : 0u;
+            vm1 |= cw;
+            vm2 |= (unsigned)(ho + p.dil) < (unsigned)p.H ? cw : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wr * (MI * 16) + mi * 16 + j;
+            if (m < p.M) {
+                const int n_img = m / p.HW;
+                const int rem = m - n_img * p.HW;
+                const int ho = rem / p.W, wo = rem - ho * p.W;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int hi = ho + (tap / 3 - 1) * p.dil, wi = wo + (tap % 3 - 1) * p.dil;
+                    const unsigned ok = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? 1u : 0u;
+                    if (tap < 3)
+                        vm0 |= ok << (tap * 9 + mi);
+                    else if (tap < 6)
+                        vm1 |= ok << ((tap - 3) * 9 + mi);
+                    else
+                        vm2 |= ok << ((tap - 6) * 9 + mi);
+                }
+            }
+        }
+    }
+
     vm_wait<2 * (P_NW - 1)>();
     asm volatile("s_barrier" ::: "memory");
     unsigned long st_c0 = 0, st_r0 = 0;
     if constexpr (DBG & 4) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0)::"memory");
     unsigned xa = x_addr_of(0, 0), xan = 0;
     VKP_READ_W(wa, 0u);
-    VKP_DSR(xw[0], xa, 0);
-    VKP_DSR(xw[1], xa, 1024);
-    VKP_DSR(xw[2], xa, 2048);
+    {
+        [[maybe_unused]] const unsigned tw0 = tap_word(VKP_IC(0));
+        VKP_DSRX(xw[0], xa, 0, tw0, 0, 0);
+        VKP_DSRX(xw[1], xa, 1024, tw0, 0, 1);
+        VKP_DSRX(xw[2], xa, 2048, tw0, 0, 2);
+    }
     pre(F_{}, VKP_IC(0), VKP_IC(0), xa, xan, wa);
     // CS is even: stages go in pairs (18 steps, so the roles of the two fragment sets repeat per pair)
     int cs = 0;
@@ -348,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     VKP_UNIT(T_{}, T_{}, 11) VKP_UNIT(T_{}, T_{}, 12) VKP_UNIT(T_{}, T_{}, 13) VKP_UNIT(T_{}, T_{}, 14) VKP_UNIT(T_{}, T_{}, 15)
     VKP_UNIT(T_{}, T_{}, 16) VKP_UNIT(T_{}, T_{}, 17)
     {
-        const unsigned tm = tap_mask(VKP_IC(8));
+        const unsigned tm = ZROW ? 0u : tap_mask(VKP_IC(8));
         VKP_MMA_ROW(5, xw[1], wb, tm);
         VKP_MMA_ROW(6, xw[2], wb, tm);
         VKP_MMA_ROW(7, xw[3], wb, tm);
@@ -359,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
 #undef VKP_UNIT
 #undef VKP_IC
 #undef VKP_DSR
+#undef VKP_DSRX
 #undef VKP_WAIT3
 #undef VKP_WAIT4
 #undef VKP_MMA_ROW
@@ -577,14 +647,14 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
 #ifdef VK_ABLATION
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
 #endif
-    const int smem = 2 * pp * 128 * 64 + P_NW * P_WSLOT;
+    const int smem = 2 * pp * 128 * 64 + P_NW * P_WSLOT + (pp == 3 ? 256 : 0);      // PP = 3: + the zero row
     k.stamps = nullptr;
 #define VKP_LAUNCH(PP_, DBG_, TAG_, MI_)                                                                                                   \
     do {                                                                                                                                   \
         static bool attr_ = false;                                                                                                         \
         if (!attr_) {                                                                                                                      \
             VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_panel_kernel<PP_, DBG_, TAG_, MI_>),                  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_ * 128 * 64 + P_NW * P_WSLOT));            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_ * 128 * 64 + P_NW * P_WSLOT + (PP_ == 3 ? 256 : 0)));            \
             attr_ = true;                                                                                                                  \
         }                                                                                                                                  \
         hipLaunchKernelGGL((conv3x3_panel_kernel<PP_, DBG_, TAG_, MI_>), grid, block, smem, stream, k);                                     \
@@ -610,6 +680,12 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
         VKP_LAUNCH(3, 8, 0, 8);
     else if (mi == 8 && pp == 3 && dbg == 1)
         VKP_LAUNCH(3, 1, 0, 8);
+    else if (mi == 9 && pp == 3 && dbg == 1)
+        VKP_LAUNCH(3, 1, 0, 9);
+    else if (mi == 9 && pp == 3 && dbg == 16)
+        VKP_LAUNCH(3, 16, 0, 9);
+    else if (mi == 9 && pp == 3 && dbg == 32)
+        VKP_LAUNCH(3, 32, 0, 9);
     else
 #endif
     if (mi == 8 && pp == 3 && a.concurrent)
