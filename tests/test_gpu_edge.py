@@ -149,3 +149,27 @@ def test_configs0_call_shape_full_size():
         matched += int(d[j] <= 1.0 and int(o16["obj_ids"][0, i]) == int(out["obj_ids"][0, j]))
     print(f"[configs[0], fp16 vs fp32 strict, image 0] {matched} of {c16} detections matched by box (1 px) and class")
     assert matched >= c16 // 2
+
+
+def test_head_chunk_beyond_4gib_keeps_the_separate_mean():
+    """ResNeXt 32x8d head (2048 mid channels) over 9600 RoIs in ONE chunk: the conv3 input of the last block is 7.7 GB, past
+    the 32-bit byte offsets of the fused conv3 + spatial-mean kernels.  The plan must fall back to the separate mean kernel
+    (it used to fail the forward with EINVAL: found by `bench.py --arch x152` at batch 32) and give the same detections and
+    features as two chunks of 4800 RoIs, which take the fused form."""
+    cfg = vg_c4_config(depth=50, num_groups=32, width_per_group=8, post_nms_topk=800, detections=36)      # 12 images x 800 = 9600 RoIs
+    sd = make_state_dict(cfg, seed=77)
+    x = torch.from_numpy(synthetic_images(12, 320, 416, seed=5))
+    sizes = torch.tensor([[320, 416]] * 12)
+    m = FRCNN(cfg, precision="fp16").load_state_dict(sd).eval()
+    outs = []
+    for chunk in (4800, 9600):
+        m.set_option("head_chunk", chunk)
+        m(x, sizes)
+        outs.append({k: v.cpu() for k, v in m.forward_padded().items()})
+    a, b = outs
+    for k in ("obj_ids", "attr_ids", "preds_per_image"):
+        assert torch.equal(a[k], b[k]), k
+    # fused: exact sums of the f16 outputs rounded once; separate kernel: fp32 running mean of the same f16 values
+    ef, eb = G.rel_err(b["roi_features"], a["roi_features"]), G.rel_err(b["boxes"], a["boxes"])
+    print(f"\n[one 9600-RoI chunk vs two of 4800] roi_features {ef:.2e} boxes {eb:.2e}")
+    assert ef <= 1e-5 and eb <= 1e-5

@@ -320,9 +320,14 @@ static void to_dt(const float *src, size_t n, vk_dtype dt, void *dst) {
 // ---- arena ----
 // fp16 fast mode: `box_features.mean(dim=[2,3])` (frcnn.py:1401) is folded into the last Res5 conv3's epilogue when
 // a 128-row tile cannot span more than two RoIs (14x14 maps; RES5HALVE's 7x7 maps take the separate kernel)
-static bool fused_mean_ok(const vk_handle *h, int P) {
+// `rows`: pixels of one Res5 chunk.  The kernels of the fused form address the conv3 input with 32-bit byte offsets
+// (conv_duo_pool_ok): a chunk whose [rows x mid channels] f16 tensor reaches 4 GiB (ResNeXt-152 32x8d at 9600 RoIs: 7.7 GB)
+// keeps the separate mean kernel instead of failing the forward.
+static bool fused_mean_ok(const vk_handle *h, int P, size_t rows) {
     static const bool off = getenv("VK_NO_FUSED_MEAN") != nullptr;      // A/B switch
-    return !off && h->dt == VK_F16 && h->cfg.res5_halve == 0 && P * P >= 128 && P * P <= 255 && h->res5_c % 256 == 0;
+    const long mid5 = (long)h->cfg.num_groups * h->cfg.width_per_group * 8;
+    return !off && h->dt == VK_F16 && h->cfg.res5_halve == 0 && P * P >= 128 && P * P <= 255 && h->res5_c % 256 == 0 &&
+           (long)rows * mid5 * 2 < (1L << 32);
 }
 
 struct Carver {
@@ -426,7 +431,7 @@ static Plan make_plan(vk_handle *h, char *base, int N, int H, int W, int D) {
     p.h_sc = cv.take(rows * h->res5_c * es);
     p.pool_part = nullptr;
     // + one tile: two half-chunks on two streams keep separate partials and each rounds its tile count up
-    if (fused_mean_ok(h, p.P)) p.pool_part = (float *)cv.take(conv_duo_pool_part_bytes((long)rows + 128, h->res5_c));
+    if (fused_mean_ok(h, p.P, rows)) p.pool_part = (float *)cv.take(conv_duo_pool_part_bytes((long)rows + 128, h->res5_c));
     p.feat = (float *)cv.take((size_t)p.K * h->res5_c * sizeof(float));
     const size_t pes = dtype_size(h->pdt);
     p.featT = cv.take((size_t)p.K * h->res5_c * pes);
