@@ -84,6 +84,8 @@ def stage_fractions(st, B, R, arch):
 
 PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 PMC_MFMA_FILES = ("r03_pmc_mfma.json",)
+POWER_CEILING = {"mfma_registers_only": 1903, "with_panel_kernel_data_movement": 1572, "with_conv_gemm4_data_movement": 1513,
+                 "package_watts": "1255-1315 of 1400", "source": "profiles/r03_g_mfma_power.txt"}
 
 
 def pmc_traffic(batch, proposals, kernel):
@@ -525,6 +527,9 @@ def main():
                          # traffic_alg_bytes are the algorithmic bytes of exactly those, alg_bytes_per_launch the average over ALL launches
                          "traffic_launches": traffic_sym, "traffic_alg_bytes": traffic_alg,
                          "mfma_busy": mfma_busy, "mfma_busy_source": mfma_src,
+                         # the chip runs this step at its package power limit: what f16 MFMA SUSTAINS on random operands,
+                         # measured by tools/micro/mfma_power.hip -- `peak` / `frac` stay the nominal issue peak of the guide
+                         "power_limited_sustained_tflops": POWER_CEILING,
                          "alg_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "alg_gflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e9, 2),
                          "kernel": f"{dom_name} ({dom_desc}, f16 in / f32 acc; all its launches in the timed region)",
