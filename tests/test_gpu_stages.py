@@ -796,3 +796,31 @@ def test_roi_outputs_golden(kat, tag):
         assert G.rel_err(bufs["attr_probs"][i, :n].cpu(), kat[f"{tag}/attr_probs_{i}"]) <= 2e-6
         assert G.rel_err(bufs["boxes"][i, :n].cpu(), kat[f"{tag}/boxes_{i}"]) <= 2e-6
         assert (bufs["roi_features"][i, n:] == 0).all() and (bufs["boxes"][i, n:] == 0).all()
+
+
+@pytest.mark.parametrize("name,switch,shape", [
+    ("panel 3x3", "VK_PANEL_DYNAMIC", (5400, 14, 14, 512, 512, 3, 2, 2)),        # 7350 tiles of 288 pixels x 2 column tiles
+    ("gemm4 1x1", "VK_GEMM4_DYNAMIC", (5400, 14, 14, 1024, 512, 1, 0, 1)),       # 8270 tiles on 256 persistent workgroups
+])
+def test_dynamic_tile_tail_is_bit_identical(monkeypatch, name, switch, shape):
+    """Long launches hand their last tiles out through an atomic counter (the XCDs of a chip differ in speed).  Which workgroup
+    computes a tile must not change a bit: the same launch with every tile static, twice with the tail (the hand-out order differs
+    from run to run), at a size that has a tail."""
+    N, H, W, cin, cout, k, pad, dil = shape
+    g = np.random.Generator(np.random.PCG64(3))
+    w = (g.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+    wd, bd = G.pack_conv(w, None, g.standard_normal(cout).astype(np.float32) * 0.1, L.VK_F16)
+    torch.manual_seed(1)
+    x = torch.randn((N, H, W, cin), device=G.DEV).half()
+
+    def run():
+        y = torch.full((N, H, W, cout), float("nan"), dtype=torch.float16, device=G.DEV)
+        L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), None, G.P(y), cout, cout, k, k, 1, pad, dil, 1, 1, L.VK_F16, L.VK_F16, G.stream())
+        torch.cuda.synchronize()
+        return y
+    monkeypatch.setenv(switch, "0")
+    ref = run()
+    assert torch.isfinite(ref).all()
+    monkeypatch.delenv(switch)
+    for _ in range(2):
+        assert torch.equal(run(), ref), name

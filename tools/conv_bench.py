@@ -42,6 +42,7 @@ def main():
     names = sys.argv[1:] or list(SHAPES)
     iters = int(os.environ.get("ITERS", "10"))
     g = np.random.Generator(np.random.PCG64(0))
+    torch.manual_seed(0)
     for name in names:
         N, H, W, cin, cout, k, stride, pad, dil, use_res = SHAPES[name]
         w = (g.standard_normal((cout, cin, k, k)) * (2.0 / (cin * k * k)) ** 0.5).astype(np.float32)
@@ -56,6 +57,12 @@ def main():
             L.call("vk_conv2d", G.P(x), N, H, W, cin, G.P(wd), G.P(bd), G.P(res), G.P(y), cout, cout, k, k, stride, pad,
                    dil, 1, 1, L.VK_F16, L.VK_F16, G.stream())
         M = N * Ho * Wo
+        if os.environ.get("CHECKSUM") == "1":       # two builds / two switch settings must give the same bits: compare these lines
+            run()
+            torch.cuda.synchronize()
+            v = y.view(torch.int16).to(torch.int64)
+            print(f"{name:12s} checksum {int(v.sum())} {int((v * (torch.arange(v.numel(), device=v.device).view(v.shape) % 65521)).sum())}")
+            continue
         if variants:      # interleaved A/B rounds in ONE process on ONE device (cdna guide rule 24)
             res_ms = {v: [] for v in variants}
             for rnd in range(int(os.environ.get("ROUNDS", "5"))):

@@ -61,6 +61,12 @@ def main():
               f"{(rows[:, 3].max() - rows[:, 3].min()) / 100:.1f} us, end spread {(rows[:, 4].max() - rows[:, 4].min()) / 100:.1f} us")
         print(f"  per tile (us): zero + wait for stage 0 {np.median(rows[:, 5] / tiles) / 100:.2f}, K loop {np.median(rows[:, 6] / tiles) / 100:.2f}, "
               f"epilogue incl. its store acknowledgements {np.median(rows[:, 7] / tiles) / 100:.2f}  ({np.median(tiles):.0f} tiles per workgroup)")
+        # where the end spread comes from: a workgroup's tiles all run on one XCD (blockIdx mod 8)
+        end = (rows[:, 4] - rows[:, 3].min()) / 100
+        wg = rows[:, 0].astype(int)
+        per = [(x, end[wg % 8 == x].mean(), end[wg % 8 == x].min(), end[wg % 8 == x].max(), np.median(tiles[wg % 8 == x])) for x in range(8)]
+        print("  end of a workgroup after the first start (us), by XCD: " + "  ".join(f"{x}: {m:.0f} ({lo:.0f}-{hi:.0f}, {t:.0f} tiles)" for x, m, lo, hi, t in per))
+        print(f"  idle CU time behind the workgroups' ends: {100 * (end.max() - end.mean()) / end.max():.1f} % of the kernel")
     print(f"  MFMA peak at this clock: {clk * 1024 * 1024 / 1e12:.0f} TFLOP/s")
 
 

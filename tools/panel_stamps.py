@@ -46,14 +46,21 @@ def main():
     torch.cuda.synchronize()
     del os.environ["VK_PANEL_STAMPS"]
     rows = np.array([[int(v) for v in ln.split()] for ln in open(out) if not ln.startswith("#")], dtype=np.float64)
+    rows = rows[rows[:, 3] > 0]          # spare workgroups of a dynamic tail leave no stamp
     cyc, kt, wt, pre = rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 4]
     steps = 9 * cin // 32
     clk = np.median(cyc / kt) * 100e6
     print(f"{name}: {len(rows)} workgroups, {steps} steps each; in-kernel clock {clk / 1e9:.3f} GHz")
-    print(f"  K loop: median {np.median(cyc):.0f} cycles = {np.median(cyc) / steps:.0f} per step (1024 = matrix pipe always busy: "
+    print(f"  K loop: median {np.median(cyc):.0f} cycles = {np.median(cyc) / steps:.0f} per step (1024 per 32 MFMAs per wave = matrix pipe always busy; 36 per wave and step with 288-pixel tiles: "
           f"{1024 * steps / np.median(cyc) * 100:.1f} %)")
     print(f"  per workgroup (us): before the K loop {np.median(pre) / 100:.2f}, K loop {np.median(kt) / 100:.2f}, after it "
           f"{np.median(wt - kt - pre) / 100:.2f} (epilogue incl. store acknowledgements): K loop = {np.median(kt / wt) * 100:.1f} % of the workgroup")
+    if rows.shape[1] >= 7:      # when each XCD (blockIdx mod 8) runs dry: its share of the grid is fixed by the dispatcher
+        wg, t0, t1 = rows[:, 0].astype(int), rows[:, 5], rows[:, 6]
+        span = (t1.max() - t0.min()) / 100
+        ends = [(t1[wg % 8 == x].max() - t0.min()) / 100 for x in range(8)]
+        print(f"  kernel span {span:.1f} us; last workgroup end by XCD (us): " + " ".join(f"{e:.0f}" for e in ends) +
+              f"; CU time idle behind them: {100 * (1 - np.mean(ends) / max(ends)):.1f} % of the kernel")
 
 
 if __name__ == "__main__":

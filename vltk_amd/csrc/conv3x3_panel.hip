@@ -45,7 +45,14 @@ struct PanelK {
     int wrow_bytes;           // 9 * Cin * 2
     int relu;
     int m_tiles, n_tiles;
-    unsigned long *stamps;    // DBG & 4 builds: 4 words per workgroup
+    unsigned long *stamps;    // DBG & 4 builds: 6 words per workgroup
+    // Dynamic tail (round 3; two-panel launches of many rounds only).  The dispatcher gives every XCD the same number of workgroups
+    // (blockIdx mod 8) and the XCDs of one chip differ by ~4.5 % in speed at the power limit (stamps: the last workgroup of the slowest
+    // ends 300 us after the fastest's on a 7.1 ms launch, 2 % of the CU time idle).  Workgroups [0, static_tiles) take the tile of their
+    // index as before; the grid carries `total - static_tiles` + spare further workgroups, each of which takes the next tail tile from an
+    // atomic counter when it STARTS (so a fast XCD does more of them) and leaves at once when none is left.
+    unsigned *tile_ctr;       // nullptr: every workgroup is its own tile
+    int static_tiles;
 };
 
 constexpr int P_NW = 6;                     // weight ring slots
@@ -105,9 +112,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     constexpr bool ZROW = PP == 3;
     constexpr int ZOFF = WBASE + P_NW * P_WSLOT;
 
-    const int bid = blockIdx.x, nwg = gridDim.x;
+    int bid = blockIdx.x;
+    const int nwg = p.m_tiles * p.n_tiles;        // tiles (== gridDim.x unless the launch has a dynamic tail)
     unsigned long st_k0 = 0;
     if constexpr (DBG & 4) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k0)::"memory");
+    if constexpr (PP == 3) {
+        if (p.tile_ctr && bid >= p.static_tiles) {               // (uniform) one atomic per workgroup, through the spare LDS behind the zero row
+            int *mail = reinterpret_cast<int *>(smem + 2 * PP * 128 * 64 + P_NW * P_WSLOT + 128);
+            if (threadIdx.x == 0) *mail = p.static_tiles + (int)atomicAdd(p.tile_ctr, 1u);
+            __syncthreads();
+            bid = __builtin_amdgcn_readfirstlane(*mail);
+            if (bid >= nwg) return;
+        }
+    }
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int n_tile = t_ % p.n_tiles, m_tile = t_ / p.n_tiles;
@@ -561,11 +578,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
         unsigned long st_k1;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_k1)::"memory");
         if (threadIdx.x == 0) {
-            unsigned long *o = p.stamps + (long)bid * 4;
+            unsigned long *o = p.stamps + (long)blockIdx.x * 6;
             o[0] = st_c1 - st_c0;       // K loop, core cycles
             o[1] = st_r1 - st_r0;       // K loop, 10 ns ticks
             o[2] = st_k1 - st_k0;       // whole workgroup, 10 ns ticks
             o[3] = st_r0 - st_k0;       // start .. K loop start
+            o[4] = st_k0;               // absolute start / end (10 ns ticks): which XCD finishes when
+            o[5] = st_k1;
         }
     }
 }
@@ -643,7 +662,18 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
         e1 = tm->get();
         VK_CHECK_HIP(hipEventRecord(e0, stream));
     }
-    const dim3 grid(k.m_tiles * k.n_tiles), block(512);
+    const int total_tiles = k.m_tiles * k.n_tiles;
+    k.tile_ctr = nullptr;
+    k.static_tiles = total_tiles;
+    int n_wgs = total_tiles;
+    const char *dyn_env = getenv("VK_PANEL_DYNAMIC");                        // "0": every tile static (A/B switch and bit-identity test; re-read per call)
+    const bool dyn_off = dyn_env && dyn_env[0] == '0';
+    if (!dyn_off && pp == 3 && total_tiles >= 16 * 256) {          // many rounds on every CU: the last sixteenth is handed out dynamically
+        VK_TRY(acquire_tile_counter(stream, &k.tile_ctr));
+        k.static_tiles = total_tiles * 15 / 16 / 8 * 8;             // (a multiple of 8: whole rounds of the XCD map; even: column-tile pairs stay together)
+        n_wgs = total_tiles + (total_tiles / 32 + 63) / 64 * 64;    // spare workgroups: an XCD 3 % faster than the mean can take 3 % more tiles
+    }
+    const dim3 grid(n_wgs), block(512);
 #ifdef VK_ABLATION
     const int dbg = getenv("VK_CONV256_DBG") ? atoi(getenv("VK_CONV256_DBG")) : 0;
 #endif
@@ -661,19 +691,22 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     } while (0)
 #ifdef VK_ABLATION      // stamp / timing-only (dbg 1: WRONG results) / LDS-epilogue builds: tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_PANEL_STAMPS"); sf && pp == 3) {   // diagnostic: one stamped launch (halo-64 / 48 build), 4 words per workgroup appended to the file
-        const size_t nb = (size_t)grid.x * 4 * sizeof(unsigned long);
+        const size_t nb = (size_t)grid.x * 6 * sizeof(unsigned long);
         VK_CHECK_HIP(hipMalloc((void **)&k.stamps, nb));
+        VK_CHECK_HIP(hipMemset(k.stamps, 0, nb));                 // (spare workgroups of a dynamic tail leave without a stamp)
         if (mi == 9)
             VKP_LAUNCH(3, 4, 0, 9);
         else
             VKP_LAUNCH(3, 4, 0, 8);
         VK_CHECK_HIP(hipStreamSynchronize(stream));
-        std::vector<unsigned long> h((size_t)grid.x * 4);
+        std::vector<unsigned long> h((size_t)grid.x * 6);
         VK_CHECK_HIP(hipMemcpy(h.data(), k.stamps, nb, hipMemcpyDeviceToHost));
         VK_CHECK_HIP(hipFree(k.stamps));
         if (FILE *f = fopen(sf, "a")) {
-            fprintf(f, "# wg k_loop_cycles k_loop_ticks workgroup_ticks ticks_before_k_loop (tick = 10 ns)\n");
-            for (unsigned w = 0; w < grid.x; ++w) fprintf(f, "%u %lu %lu %lu %lu\n", w, h[(size_t)w * 4], h[(size_t)w * 4 + 1], h[(size_t)w * 4 + 2], h[(size_t)w * 4 + 3]);
+            fprintf(f, "# wg k_loop_cycles k_loop_ticks workgroup_ticks ticks_before_k_loop start_tick end_tick (tick = 10 ns)\n");
+            for (unsigned w = 0; w < grid.x; ++w)
+                fprintf(f, "%u %lu %lu %lu %lu %lu %lu\n", w, h[(size_t)w * 6], h[(size_t)w * 6 + 1], h[(size_t)w * 6 + 2], h[(size_t)w * 6 + 3], h[(size_t)w * 6 + 4],
+                        h[(size_t)w * 6 + 5]);
             fclose(f);
         }
     } else if (mi == 8 && pp == 3 && dbg == 8)

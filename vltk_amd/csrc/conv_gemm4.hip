@@ -20,6 +20,9 @@
 #include <type_traits>
 #include <vector>
 
+#include <atomic>
+#include <mutex>
+
 #include "vk_common.h"
 
 namespace vk {
@@ -45,6 +48,11 @@ struct Gemm4K {
     int relu;
     int m_tiles, n_tiles;
     unsigned long *stamps;   // STAMP builds only: 4 words per workgroup
+    // Dynamic tail (round 3): tiles [0, static_tiles) are walked bid, bid + grid, ... as before; the rest are handed out by an atomic
+    // counter, whichever workgroup asks first.  The XCDs of one chip differ by 4 - 6 % in speed under the power limit (stamps:
+    // tools/gemm4_stamps.py), and with a fixed share per workgroup the fast ones sat idle for 3.4 % of the K = 2048 launches.
+    unsigned *tile_ctr;      // nullptr: every tile is static
+    int static_tiles;
 };
 
 constexpr int G_ROWB = 64, G_NSLOT = 4;
@@ -309,7 +317,13 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     unsigned long ph_loop = 0, ph_epi = 0, ph_tiles = 0, ts = 0, ts_first = 0, te_last = 0, t_c0 = 0, t_r0 = 0;   // STAMP
     if constexpr (STAMP) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_first)::"memory");
     for (int tt = bid;;) {
-        const int nt = tt + (int)gridDim.x;
+        int nt = tt + (int)gridDim.x;
+        if (p.tile_ctr && nt >= p.static_tiles) {            // (uniform) the tail: one atomic per workgroup and tile, through LDS
+            int *mail = reinterpret_cast<int *>(smem + G_SMEM + p.ldy * 4);
+            if (tid == 0) *mail = p.static_tiles + (int)atomicAdd(p.tile_ctr, 1u);
+            __syncthreads();
+            nt = __builtin_amdgcn_readfirstlane(*mail);
+        }
         // (computed by scalar asm: left to hipcc, the flag lives as a lane mask and every branch on it costs a VALU pair -- which it
         // places right behind the MFMAs of the K loop)
         asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(has_next) : "s"(nt), "s"(total_tiles) : "scc");
@@ -459,6 +473,28 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     }
 }
 
+// A zeroed 32-bit device word for ONE launch's dynamic tile tail: a ring of 4096 words per device, reset on the launch's stream.
+// (A slot comes round again after 4096 launches; a handle keeps at most four forwards of a few hundred launches in flight.)
+int acquire_tile_counter(hipStream_t stream, unsigned **ctr) {
+    static unsigned *ring[VK_MAX_DEVICES];
+    static std::atomic<unsigned> next[VK_MAX_DEVICES];
+    static std::mutex mu;
+    int dev = 0;
+    VK_CHECK_HIP(hipGetDevice(&dev));
+    VK_REQUIRE(dev >= 0 && dev < VK_MAX_DEVICES, VK_EINVAL, "device %d beyond VK_MAX_DEVICES", dev);
+    if (!ring[dev]) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) {
+            unsigned *r = nullptr;
+            VK_CHECK_HIP(hipMalloc((void **)&r, 4096 * sizeof(unsigned)));
+            ring[dev] = r;
+        }
+    }
+    *ctr = ring[dev] + (next[dev].fetch_add(1) & 4095u);
+    VK_CHECK_HIP(hipMemsetAsync(*ctr, 0, sizeof(unsigned), stream));
+    return VK_OK;
+}
+
 bool conv_gemm4_eligible(const ConvArgs &a) {
     const char *v = getenv("VK_CONV_GEMM4");             // "0" disables, "2" also takes small grids (A/B switch and bit-identity tests; re-read per call)
     if (v && v[0] == '0') return false;
@@ -534,6 +570,15 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     }
     const int total_tiles = k.m_tiles * k.n_tiles;
     const int grid_wgs = total_tiles < n_cu ? total_tiles : n_cu;
+    k.tile_ctr = nullptr;
+    k.static_tiles = total_tiles;
+    const char *dyn_env = getenv("VK_GEMM4_DYNAMIC");                        // "0": every tile static (A/B switch and bit-identity test; re-read per call)
+    const bool dyn_off = dyn_env && dyn_env[0] == '0';
+    if (!dyn_off && total_tiles >= 16 * grid_wgs && a.Cout <= 4096) {     // long launches: the last eighth of a workgroup's tiles is dynamic
+        VK_TRY(acquire_tile_counter(stream, &k.tile_ctr));
+        k.static_tiles = (total_tiles / grid_wgs) * 7 / 8 * grid_wgs;
+    }
+    const size_t smem_bytes = G_SMEM + (size_t)a.Cout * 4 + 16;           // ring, bias, the tail's mailbox word
 #ifdef VK_ABLATION      // stamp / timing-only builds (WRONG results for DBG != 0): tools/ builds only (make ABLATION=1)
     if (const char *sf = getenv("VK_GEMM4_STAMPS")) {    // diagnostic: one stamped launch, 4 words per workgroup appended to the file
         const int nwg = grid_wgs;
@@ -544,11 +589,11 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
 #define VKG_DBG_CASE(D_)                                                                                                   \
     case D_:                                                                                                               \
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<true, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768)); \
-        hipLaunchKernelGGL((conv_gemm4_kernel<true, D_>), dim3(nwg), dim3(256), G_SMEM + a.Cout * 4, stream, k);                        \
+        hipLaunchKernelGGL((conv_gemm4_kernel<true, D_>), dim3(nwg), dim3(256), smem_bytes, stream, k);                        \
         break;
             VKG_DBG_CASE(1) VKG_DBG_CASE(2) VKG_DBG_CASE(3) VKG_DBG_CASE(4) VKG_DBG_CASE(8) VKG_DBG_CASE(12) VKG_DBG_CASE(13) VKG_DBG_CASE(15)
 #undef VKG_DBG_CASE
-            default: hipLaunchKernelGGL(conv_gemm4_kernel<true>, dim3(nwg), dim3(256), G_SMEM + a.Cout * 4, stream, k);
+            default: hipLaunchKernelGGL(conv_gemm4_kernel<true>, dim3(nwg), dim3(256), smem_bytes, stream, k);
         }
         VK_CHECK_HIP(hipStreamSynchronize(stream));
         std::vector<unsigned long> h((size_t)nwg * 8);
@@ -565,7 +610,7 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
         }
     } else if (getenv("VK_GEMM4_DBG") && atoi(getenv("VK_GEMM4_DBG")) == 128) {      // bisect: builtin MFMAs
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
-        hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
+        hipLaunchKernelGGL((conv_gemm4_kernel<false, 128>), dim3(grid_wgs), dim3(256), smem_bytes, stream, k);
     } else
 #endif
     if (a.concurrent) {
@@ -574,9 +619,9 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
             VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_gemm4_kernel<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G_SMEM + 32768));
             attr1 = true;
         }
-        hipLaunchKernelGGL((conv_gemm4_kernel<false, 0, 1>), dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
+        hipLaunchKernelGGL((conv_gemm4_kernel<false, 0, 1>), dim3(grid_wgs), dim3(256), smem_bytes, stream, k);
     } else {
-        hipLaunchKernelGGL(conv_gemm4_kernel<false>, dim3(grid_wgs), dim3(256), G_SMEM + a.Cout * 4, stream, k);
+        hipLaunchKernelGGL(conv_gemm4_kernel<false>, dim3(grid_wgs), dim3(256), smem_bytes, stream, k);
     }
     VK_CHECK_HIP(hipGetLastError());
     if (tm) {
