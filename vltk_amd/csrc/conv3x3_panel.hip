@@ -53,6 +53,7 @@ struct PanelK {
     // atomic counter when it STARTS (so a fast XCD does more of them) and leaves at once when none is left.
     unsigned *tile_ctr;       // nullptr: every workgroup is its own tile
     int static_tiles;
+    unsigned ctr_last;        // the launch's last fetch (one per tail workgroup): whoever draws it zeroes the word for its next user
 };
 
 constexpr int P_NW = 6;                     // weight ring slots
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_panel_kernel(PanelK p) {
     if constexpr (PP == 3) {
         if (p.tile_ctr && bid >= p.static_tiles) {               // (uniform) one atomic per workgroup, through the spare LDS behind the zero row
             int *mail = reinterpret_cast<int *>(smem + 2 * PP * 128 * 64 + P_NW * P_WSLOT + 128);
-            if (threadIdx.x == 0) *mail = p.static_tiles + (int)atomicAdd(p.tile_ctr, 1u);
+            if (threadIdx.x == 0) {
+                const unsigned v = atomicAdd(p.tile_ctr, 1u);
+                if (v == p.ctr_last) *p.tile_ctr = 0u;
+                *mail = p.static_tiles + (int)v;
+            }
             __syncthreads();
             bid = __builtin_amdgcn_readfirstlane(*mail);
             if (bid >= nwg) return;
@@ -669,9 +674,10 @@ int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream) {
     const char *dyn_env = getenv("VK_PANEL_DYNAMIC");                        // "0": every tile static (A/B switch and bit-identity test; re-read per call)
     const bool dyn_off = dyn_env && dyn_env[0] == '0';
     if (!dyn_off && pp == 3 && total_tiles >= 16 * 256) {          // many rounds on every CU: the last sixteenth is handed out dynamically
-        VK_TRY(acquire_tile_counter(stream, &k.tile_ctr));
+        VK_TRY(acquire_tile_counter(&k.tile_ctr));
         k.static_tiles = total_tiles * 15 / 16 / 8 * 8;             // (a multiple of 8: whole rounds of the XCD map; even: column-tile pairs stay together)
         n_wgs = total_tiles + (total_tiles / 32 + 63) / 64 * 64;    // spare workgroups: an XCD 3 % faster than the mean can take 3 % more tiles
+        k.ctr_last = (unsigned)(n_wgs - k.static_tiles - 1);
     }
     const dim3 grid(n_wgs), block(512);
 #ifdef VK_ABLATION

@@ -53,6 +53,7 @@ struct Gemm4K {
     // tools/gemm4_stamps.py), and with a fixed share per workgroup the fast ones sat idle for 3.4 % of the K = 2048 launches.
     unsigned *tile_ctr;      // nullptr: every tile is static
     int static_tiles;
+    unsigned ctr_last;       // the launch's last fetch (every workgroup fetches until its first miss): whoever draws it zeroes the word for its next user
 };
 
 constexpr int G_ROWB = 64, G_NSLOT = 4;
@@ -320,7 +321,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
         int nt = tt + (int)gridDim.x;
         if (p.tile_ctr && nt >= p.static_tiles) {            // (uniform) the tail: one atomic per workgroup and tile, through LDS
             int *mail = reinterpret_cast<int *>(smem + G_SMEM + p.ldy * 4);
-            if (tid == 0) *mail = p.static_tiles + (int)atomicAdd(p.tile_ctr, 1u);
+            if (tid == 0) {
+                const unsigned v = atomicAdd(p.tile_ctr, 1u);
+                if (v == p.ctr_last) *p.tile_ctr = 0u;
+                *mail = p.static_tiles + (int)v;
+            }
             __syncthreads();
             nt = __builtin_amdgcn_readfirstlane(*mail);
         }
@@ -473,9 +478,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm4_kernel(Gemm4K p) {
     }
 }
 
-// A zeroed 32-bit device word for ONE launch's dynamic tile tail: a ring of 4096 words per device, reset on the launch's stream.
-// (A slot comes round again after 4096 launches; a handle keeps at most four forwards of a few hundred launches in flight.)
-int acquire_tile_counter(hipStream_t stream, unsigned **ctr) {
+// A zeroed 32-bit device word for ONE launch's dynamic tile tail, from a ring of 256 words per device zeroed when it is allocated.
+// No reset on the stream (a memset between two kernels cost an 11 us bubble per launch): the number of fetches of a launch is known
+// in advance, and the workgroup that draws the last one writes the zero back.  (A slot comes round again after 256 launches WITH a tail; a handle keeps at most
+// four forwards of seven such launches in flight, and the wrap is exercised by every bench run.)
+int acquire_tile_counter(unsigned **ctr) {
     static unsigned *ring[VK_MAX_DEVICES];
     static std::atomic<unsigned> next[VK_MAX_DEVICES];
     static std::mutex mu;
@@ -486,12 +493,12 @@ int acquire_tile_counter(hipStream_t stream, unsigned **ctr) {
         std::lock_guard<std::mutex> lock(mu);
         if (!ring[dev]) {
             unsigned *r = nullptr;
-            VK_CHECK_HIP(hipMalloc((void **)&r, 4096 * sizeof(unsigned)));
+            VK_CHECK_HIP(hipMalloc((void **)&r, 256 * sizeof(unsigned)));
+            VK_CHECK_HIP(hipMemset(r, 0, 256 * sizeof(unsigned)));      // (synchronous: done before any launch can use a word)
             ring[dev] = r;
         }
     }
-    *ctr = ring[dev] + (next[dev].fetch_add(1) & 4095u);
-    VK_CHECK_HIP(hipMemsetAsync(*ctr, 0, sizeof(unsigned), stream));
+    *ctr = ring[dev] + (next[dev].fetch_add(1) & 255u);
     return VK_OK;
 }
 
@@ -575,8 +582,9 @@ int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream) {
     const char *dyn_env = getenv("VK_GEMM4_DYNAMIC");                        // "0": every tile static (A/B switch and bit-identity test; re-read per call)
     const bool dyn_off = dyn_env && dyn_env[0] == '0';
     if (!dyn_off && total_tiles >= 16 * grid_wgs && a.Cout <= 4096) {     // long launches: the last eighth of a workgroup's tiles is dynamic
-        VK_TRY(acquire_tile_counter(stream, &k.tile_ctr));
+        VK_TRY(acquire_tile_counter(&k.tile_ctr));
         k.static_tiles = (total_tiles / grid_wgs) * 7 / 8 * grid_wgs;
+        k.ctr_last = (unsigned)(total_tiles - k.static_tiles + grid_wgs - 1);     // the tail's tiles + one miss per workgroup
     }
     const size_t smem_bytes = G_SMEM + (size_t)a.Cout * 4 + 16;           // ring, bias, the tail's mailbox word
 #ifdef VK_ABLATION      // stamp / timing-only builds (WRONG results for DBG != 0): tools/ builds only (make ABLATION=1)

@@ -83,7 +83,7 @@ bool conv3x3_panel_eligible(const ConvArgs &a);           // conv3x3_panel.hip (
 int launch_conv3x3_panel(const ConvArgs &a, hipStream_t stream);
 bool conv_gemm4_eligible(const ConvArgs &a);              // conv_gemm4.hip (1x1, K >= 1024, one or two inputs: 256x256 tile, four waves of 128x128)
 int launch_conv_gemm4(const ConvArgs &a, hipStream_t stream);
-int acquire_tile_counter(hipStream_t stream, unsigned **ctr);     // a zeroed device word for one launch's dynamic tile tail (conv_gemm4.hip)
+int acquire_tile_counter(unsigned **ctr);     // a zeroed device word for one launch's dynamic tile tail; its last fetch zeroes it again (conv_gemm4.hip)
 bool conv256_dual_ok(const ConvArgs &a);                  // conv_mfma256.hip (dual-source 1x1 with a long K: 256x256 tile)
 bool conv_duo_eligible(const ConvArgs &a);                // conv_mfma_duo.hip (1x1 convs: 128x256 tile, two workgroups per CU)
 int launch_conv_duo(const ConvArgs &a, hipStream_t stream);
