@@ -64,7 +64,7 @@ __device__ __forceinline__ void ws_vm_wait() {
 constexpr int WS_BM = 64;                    // rows per tile
 
 // KC = K / 32 MFMA steps (4, 8, 16)
-// DBG: timing-only ablation builds (VK_WS_DBG, WRONG results): 1 no epilogue, 2 no MFMA, 4 no pixel DMA, 8 no residual DMA
+// DBG: timing-only ablation builds (VK_WS_DBG, WRONG results): 1 no epilogue, 2 no MFMA, 4 no pixel DMA, 8 no residual DMA, 64 epilogue without its stores
 // NW: waves per workgroup.  4 = one wave per SIMD with 64 channels each (256 weight registers); 8 = two waves per SIMD with
 // 32 channels each (128 weight registers, <= 256 registers per lane), so that one wave's barrier / LDS / epilogue latencies
 // are covered by the other wave of the SIMD
@@ -230,7 +230,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) scr[(gp * 4 + k) * 64 + ((pt * 16 + jp + gp * 16) & 63)] = ov[k];
                 } else {
-                    if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
+                    if constexpr (DBG & 64) {
+                        asm volatile("" ::"v"(o));
+                    } else {
+                        if (FULL || m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
+                    }
                 }
             }
         }
@@ -364,6 +368,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
         }
         // ---- epilogue: (acc + bias) + residual, ReLU, f16.  The residual pieces are older than the SPT stages requested since ----
         if constexpr (DBG & 32) t_a = __builtin_amdgcn_s_memtime();
+        if constexpr (DBG & 1) {                 // (keep the MFMAs alive in the timing-only build without an epilogue)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[pt][ni]));
+        }
         if (!(DBG & 1)) {
             if (p.res) {
                 if ((it + 1) * SPT - 1 + WS_D < total)
@@ -553,7 +563,7 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         else if (nw == 8) {
             switch (dbg) {
                 VKW_DBG_CASE(8, 1) VKW_DBG_CASE(8, 2) VKW_DBG_CASE(8, 3) VKW_DBG_CASE(8, 4) VKW_DBG_CASE(8, 8) VKW_DBG_CASE(8, 12)
-                VKW_DBG_CASE(8, 15)
+                VKW_DBG_CASE(8, 15) VKW_DBG_CASE(8, 64) VKW_DBG_CASE(8, 9) VKW_DBG_CASE(8, 72)
                 default: st = launch_ws<16, 8>(k, stream); break;
             }
         } else {
