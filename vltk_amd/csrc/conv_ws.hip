@@ -424,213 +424,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_ws_kernel(WsK p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// PIPELINED EPILOGUE (round 3): the bottlenecks' conv3 (stride 1, one source, residual + ReLU, K = 256 / 512), eight waves.
-// Timing-only builds of the kernel above put Res5's conv3 at 3.14 ms for the K loop with its pixel DMA and 1.25 ms for the epilogue ON
-// TOP of it: every wave of the workgroup is in the same phase, so the matrix pipe idles while 15 GB of residual / output
-// move and the memory side idles while it does not.  Here tile i's epilogue runs INSIDE tile i + 1's K loop, one unit (32 channels x
-// 16 pixels: one residual read, one store) per stage (two at K = 256), between two MFMA groups:
-//   * two accumulator sets, alternating per tile (the tile loop is unrolled by two so that both are plain registers);
-//   * two residual buffers per wave (tile i's rows are read while tile i + 1's arrive), paid with one ring slot: five slots, the DMA
-//     four stages ahead;
-//   * the fragments of a stage are read one MFMA group ahead instead of all sixteen up front (registers: 128 of weights at K = 512).
-// Same arithmetic, same K order, same bits as conv_ws_kernel.  vmcnt: the queue now also holds the units' stores and the residual
-// pieces between a stage's request and its wait; the waits count them (exactly from the third tile on, conservatively before).
-template <int KC>
-__global__ __launch_bounds__(512, 1) void conv_ws_pipe_kernel(WsK p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(KC == 8 || KC == 16, "K = 256 / 512");
-    constexpr int NW = 8, KSL = 4, PITCH = 256, WS_SLOT = WS_BM * PITCH, WS_NS = 5, WS_D = 4, RING = WS_NS * WS_SLOT;
-    constexpr int SPT = KC / KSL, NI = 2, WCH = 32, PPW = WS_SLOT / 1024 / NW, RPW = 32 / NW, LPR = PITCH / 16;
-    constexpr int UPS = 4 / SPT;                  // epilogue units per stage
-    // entries of the vmcnt queue between a stage's second request and its wait: the later stages' pieces, the residual pieces of the tile
-    // starts in between, and (from the third tile on) the units' stores
-    constexpr int N_PLAIN = PPW * (WS_D - 1) + RPW * (WS_D / SPT), N_UNITS = N_PLAIN + UPS * (WS_D - 1);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, j = lane & 15;
-    const int wg = blockIdx.x, per_xcd = gridDim.x >> 3;
-    const int xcd = wg & 7, i = wg >> 3;
-    const int n_tile = i % p.n_tiles, lane_m = i / p.n_tiles;
-    const int lanes_x = per_xcd / p.n_tiles;
-    const int ML = 8 * lanes_x;
-    const int first = xcd * lanes_x + lane_m;
-    const int ntw = first < p.m_tiles ? (p.m_tiles - first + ML - 1) / ML : 0;
-    const int n0 = n_tile * 256;
-    const int total = ntw * SPT;
-
-    half8 wf[NI][KC];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int co = n0 + wave * WCH + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
-        const char *wr = p.w + (long)co * p.kbytes + g * 16;
-#pragma unroll
-        for (int ks = 0; ks < KC; ++ks) wf[ni][ks] = *reinterpret_cast<const half8 *>(wr + ks * 64);
-    }
-    char *res0 = smem + RING + wave * (WS_BM * WCH * 2);          // + buffer * 32 KiB
-    float *bias_lds = reinterpret_cast<float *>(smem + RING + 2 * 8 * WS_BM * WCH * 2);
-    if (tid < 256) bias_lds[tid] = p.bias[n0 + tid];
-    ws_vm_wait<0>();
-    __syncthreads();
-
-    auto request = [&](int q_, int qlo, int qhi) {
-        const int it = q_ / SPT, st = q_ - it * SPT;
-        const int m0 = (first + it * ML) * WS_BM;
-        char *dst = smem + (q_ % WS_NS) * WS_SLOT + wave * PPW * 1024;
-        int ln = lane;                            // opaque copy: hipcc otherwise keeps the two pieces' 64-bit lane addresses live across the
-        asm volatile("" : "+v"(ln));              // whole kernel and spills them -- a scratch reload is a vector-memory access with a vmcnt(0)
-        const int drow = ln / LPR, dslot = ln & (LPR - 1);
-#pragma unroll
-        for (int q = qlo; q < qhi; ++q) {
-            const int row = (wave * PPW + q) * (64 / LPR) + drow;
-            const int m = min(m0 + row, p.M - 1);
-            VKW_GLDS16(p.x + (long)m * p.kbytes + st * PITCH + ((dslot ^ (row & (LPR - 1))) << 4), dst + q * 1024);
-        }
-    };
-    for (int q_ = 0; q_ < WS_D && q_ < total; ++q_) request(q_, 0, PPW);
-
-    auto rsw = [](int r) { return (0x1320 >> (((r >> 2) & 3) * 4)) & 3; };
-
-    // unit u (= pixel tile u) of tile `itp`: accumulators `ap`, residual rows in buffer `pb`
-    auto unit = [&](const floatx4 (&ap)[4][NI], int itp, int pb, int u) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int jj = ln & 15, gg = ln >> 4;
-        const int row = u * 16 + jj;
-        const int ch = wave * WCH + gg * 8;
-        const half8 rr = *reinterpret_cast<const half8 *>(res0 + pb * 32768 + row * 64 + ((gg ^ rsw(row)) << 4));
-        // in two halves of four channels (registers: K = 512 leaves this kernel none to spare); same operations, same order per element
-        half4 h0, h1;
-        {
-            const floatx4 b0 = *reinterpret_cast<const floatx4 *>(bias_lds + ch);
-            floatx4 x0 = ap[u][0] + b0;
-            x0 += __builtin_convertvector(__builtin_shufflevector(rr, rr, 0, 1, 2, 3), floatx4);
-            h0 = __builtin_convertvector(x0, half4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const floatx4 b1 = *reinterpret_cast<const floatx4 *>(bias_lds + ch + 4);
-            floatx4 x1 = ap[u][1] + b1;
-            x1 += __builtin_convertvector(__builtin_shufflevector(rr, rr, 4, 5, 6, 7), floatx4);
-            h1 = __builtin_convertvector(x1, half4);
-        }
-        half8 o = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o = __builtin_elementwise_max(o, half8{0, 0, 0, 0, 0, 0, 0, 0});
-        const long m = (long)(first + itp * ML) * WS_BM + row;
-        if (m < p.M) *reinterpret_cast<half8 *>(p.y + (m * p.ldy + n0 + ch) * 2) = o;
-    };
-
-    // one tile: K loop into `ac`; the previous tile's units (accumulators `ap`, residual buffer 1 - cb) ride on its stages
-    auto tile = [&](floatx4 (&ac)[4][NI], const floatx4 (&ap)[4][NI], int it, int cb, bool have_prev) {
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) ac[pt][ni] = floatx4{0.f, 0.f, 0.f, 0.f};
-        const int m0 = (first + it * ML) * WS_BM;
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int row = q * 16 + (lane >> 2);
-            const int m = min(m0 + row, p.M - 1);
-            VKW_GLDS16(p.res + ((long)m * p.ldy + n0 + wave * 32) * 2 + (((lane & 3) ^ rsw(row)) << 4), res0 + cb * 32768 + q * 1024);
-        }
-#pragma unroll
-        for (int st = 0; st < SPT; ++st) {
-            const int gs = it * SPT + st;
-            if (gs + WS_D - 1 < total) {
-                if (it >= 2)
-                    ws_vm_wait<N_UNITS>();
-                else
-                    ws_vm_wait<N_PLAIN>();
-            } else {
-                ws_vm_wait<0>();
-            }
-            __builtin_amdgcn_s_barrier();
-            if constexpr (SPT == 2) {
-                // K = 256: a tile is two stages, so the previous tile's residual pieces are NOT older than what the stage wait lets
-                // stay in flight: count what followed them (that tile's requests and stores, this tile's residual pieces)
-                if (st == 0 && have_prev) {
-                    if (it >= 2)
-                        ws_vm_wait<SPT * (PPW + UPS) + RPW>();
-                    else
-                        ws_vm_wait<SPT * PPW + RPW>();
-                }
-            }
-            const bool more = gs + WS_D < total;
-            const char *slot = smem + (gs % WS_NS) * WS_SLOT;
-            // fragment address of (pixel tile pt, K step ksl), from an opaque copy of the lane index: nothing of it lives across the loop
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            const int jj = ln & 15, gg = ln >> 4;
-            const int xrow = jj * PITCH;
-            auto xaddr = [&](int ksl) { return xrow + (((ksl * 4 + gg) ^ jj) << 4); };
-            half8 xf[2][4];
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) xf[0][pt] = *reinterpret_cast<const half8 *>(slot + pt * 16 * PITCH + xaddr(0));
-#pragma unroll
-            for (int ksl = 0; ksl < KSL; ++ksl) {
-                // waves w and w + 4 share a SIMD and run in step (one barrier per stage): their units sit behind DIFFERENT MFMA groups, so
-                // that one of the two always has MFMAs to issue
-                const int u = SPT == 4 ? st : st * 2 + ((ksl - (wave >> 2)) >> 1);
-                const bool do_unit = have_prev && (SPT == 2 ? (ksl == (wave >> 2) || ksl == 2 + (wave >> 2)) : ksl == 1 + 2 * (wave >> 2));
-                if (ksl + 1 < KSL) {
-#pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) xf[(ksl + 1) & 1][pt] = *reinterpret_cast<const half8 *>(slot + pt * 16 * PITCH + xaddr(ksl + 1));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        ac[pt][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni][KSL * st + ksl], xf[ksl & 1][pt], ac[pt][ni], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // the unit's reads are issued BEHIND the group's MFMAs (eight of them keep the pipe busy over the LDS round trip) so that
-                // its twelve registers are not live across them; its store goes ahead of this group's request (it is the older entry)
-                if (do_unit) unit(ap, it - 1, 1 - cb, u);
-                if (more && (ksl & 1)) request(gs + WS_D, ksl >> 1, (ksl >> 1) + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    floatx4 accA[4][NI], accB[4][NI];
-    for (int it = 0; it < ntw; it += 2) {
-        tile(accA, accB, it, 0, it > 0);
-        if (it + 1 < ntw) tile(accB, accA, it + 1, 1, true);
-    }
-    // the last tile's units
-    if (ntw > 0) {
-        ws_vm_wait<0>();
-        const int itl = ntw - 1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (itl & 1)
-                unit(accB, itl, 1, u);
-            else
-                unit(accA, itl, 0, u);
-        }
-    }
-}
-
-bool conv_ws_pipe_ok(const ConvArgs &a) {
-    const char *v = getenv("VK_WS_PIPE");                // "0": the epilogue stays behind its tile (A/B switch and bit-identity test; re-read per call)
-    if (v && v[0] == '0') return false;
-    return !a.pool_part && !a.x2 && a.stride == 1 && a.res && a.relu == 1 && (a.Cin == 256 || a.Cin == 512);
-}
-
-template <int KC>
-static int launch_ws_pipe(const WsK &k, hipStream_t stream) {
-    constexpr int smem = 5 * WS_BM * 256 + 2 * 8 * WS_BM * 32 * 2 + 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_ws_pipe_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((conv_ws_pipe_kernel<KC>), dim3(256), dim3(512), smem, stream, k);
-    VK_CHECK_HIP(hipGetLastError());
-    return VK_OK;
-}
-
 // The fused-mean form (a.pool_part set) runs here when K = 512 and the column blocks tile an XCD; otherwise on the two-per-CU
 // kernel.  The per-image fp64 sums (Cout x 8 B per image) live in the workspace that kernel sizes for its per-tile partials
 // (Cout x 16 B per 128 rows: larger from 128 rows per image on, which its own eligibility asks for).  Both sides of the
@@ -757,9 +550,7 @@ int launch_conv_ws(const ConvArgs &a, hipStream_t stream) {
         const int dbg = 0;
 #define VKW_DBG_CASE(NW_, D_)
 #endif
-        if (nw == 8 && dbg == 0 && conv_ws_pipe_ok(a))
-            st = a.Cin == 256 ? launch_ws_pipe<8>(k, stream) : launch_ws_pipe<16>(k, stream);
-        else if (a.stride != 1)
+        if (a.stride != 1)
             st = a.Cin == 256 ? launch_ws<8, 8, 0, false, false, true>(k, stream) : launch_ws<16, 8, 0, false, false, true>(k, stream);
         else if (a.x2)
             st = launch_ws<4, 8, 0, false, true>(k, stream);
