@@ -685,6 +685,39 @@ def test_nms_bit_exact(n, thr, ties):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("lead", ["0", "64", "192"])
+def test_nms_two_phases_bit_exact(monkeypatch, lead):
+    """launch_nms computes the suppression masks of the leading boxes first and the rest only for images whose sweep has not reached
+    the cap (csrc/rpn.hip).  VK_NMS_LEAD forces a short first phase ("0": one phase): 6000 clustered boxes where every box may be
+    kept (vk_nms: the second phase always runs), and RPN proposals at full size from HEAVILY overlapping anchors (tiny deltas on a
+    coarse logit grid: the 300th survivor lies thousands of candidates deep) -- kept sets identical to the oracle either way."""
+    monkeypatch.setenv("VK_NMS_LEAD", lead)
+    g = _rng(4242)
+    n = 6000
+    ctr = g.uniform(0, 1300, (150, 2))
+    c = ctr[g.integers(0, len(ctr), n)] + g.normal(0, 25, (n, 2))
+    wh = g.uniform(8, 220, (n, 2))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    scores = (np.round(g.standard_normal(n) * 4) / 4).astype(np.float32)
+    np.testing.assert_array_equal(_nms_gpu(boxes, scores, 0.5), orc.nms(torch.from_numpy(boxes), torch.from_numpy(scores), 0.5).numpy())
+    N, A, Hf, Wf = 2, 15, 50, 84
+    obj = torch.from_numpy(g.standard_normal((N, A, Hf, Wf)).astype(np.float32))
+    # logits that rise towards one corner: the top candidates are neighbouring, heavily overlapping anchors
+    obj += torch.linspace(0, 40, Hf).view(1, 1, Hf, 1) + torch.linspace(0, 40, Wf).view(1, 1, 1, Wf)
+    dlt = torch.from_numpy(g.standard_normal((N, 4 * A, Hf, Wf)).astype(np.float32) * 0.02)
+    shapes = [[800, 1333], [750, 1200]]
+    from vltk_amd.weights import cell_anchors
+    cell = cell_anchors([32, 64, 128, 256, 512], [0.5, 1.0, 2.0])
+    o = FRCNNOracle(Config(vg_c4_config_dict()), {"proposal_generator.anchor_generator.cell_anchors.0": torch.from_numpy(cell)})
+    ref = o.rpn_proposals(obj, dlt, shapes)
+    got = _rpn_gpu(obj, dlt, shapes, cell, pre=6000, post=300, thr=0.7)
+    for (rb, rl), (gb, gl) in zip(ref, got):
+        assert len(gb) == len(rb)
+        np.testing.assert_array_equal(gl.numpy(), rl.numpy())
+        assert G.rel_err(gb, rb) <= 2e-6
+    print(f"\n[VK_NMS_LEAD={lead}] survivors per image: {[len(b) for b, _ in got]}")
+
+
 def test_nms_empty():
     assert len(_nms_gpu(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.5)) == 0
 

@@ -1,7 +1,7 @@
 // Micro-benchmark (GPU box): what the chip SUSTAINS in f16 MFMA on random operands -- it runs the FRCNN step at its package power
 // limit (~1300 W), so a kernel's ceiling is set by its energy per flop, not by the 2.5 PFLOP/s issue peak.
 //   variant            per 16 MFMAs (16x16x32) and wave
-//   mfma16 / mfma32    registers only: the two gfx950 f16 shapes
+//   mfma16 / mfma32    registers only: the two gfx950 f16 shapes (mfma16 also with its accumulators in AGPRs)
 //   lds R              + R ds_read_b128 (fragment reads: the panel 3x3 kernel has 5.8, conv_gemm4 4.0)
 //   dma R D            + D global_load_lds_dwordx4 of 1 KB from a 2 MiB buffer (L1 misses, L2 hits) (panel 1.1, gemm4 2.0)
 // 256 workgroups x 8 waves (2 per SIMD).   hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip && ./mfma_power [iters]
@@ -71,6 +71,21 @@ __global__ __launch_bounds__(512) void k(const _Float16 *src, const char *l2buf,
         }
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    } else if constexpr (SHAPE == 17) {
+        floatx4 acc[4][4] = {};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
     } else {
         floatx16 acc[2][2] = {};
         for (int it = 0; it < iters; ++it) {
@@ -121,7 +136,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const Var vars[] = {{"mfma16 (registers only)", k<16, 0, 0>}, {"mfma32 (registers only)", k<32, 0, 0>},
+    const Var vars[] = {{"mfma16 (registers only)", k<16, 0, 0>}, {"mfma16, accumulators in AGPRs", k<17, 0, 0>}, {"mfma32 (registers only)", k<32, 0, 0>},
                         {"mfma16 + 4 ds_read (gemm4 ratio)", k<16, 4, 0>}, {"mfma16 + 6 ds_read (panel ratio)", k<16, 6, 0>},
                         {"mfma16 + 8 ds_read", k<16, 8, 0>},
                         {"mfma16 + 6 ds_read + 1 DMA KB (panel)", k<16, 6, 2>}, {"mfma16 + 4 ds_read + 2 DMA KB (gemm4)", k<16, 4, 4>},

@@ -85,7 +85,7 @@ __device__ __forceinline__ void clip4(float b[4], float h, float w) {
 
 // ---------------------------------------------------------------------------
 // workspace per image: cand_boxes [pre][4] f32, cand_logit [pre] f32, cand_valid [pre] u8 (as i32 words), cand_count [1]
-__global__ __launch_bounds__(RPN_THREADS) void rpn_select_decode_kernel(
+__device__ __forceinline__ void rpn_select_decode_body(
     const float *__restrict__ logits, int ld_logits, const float *__restrict__ deltas, int ld_deltas, int Hf, int Wf,
     int A, const float *__restrict__ cell_anchors, const int32_t *__restrict__ image_hw, DecodeCfg cfg, int pre_topk,
     int sortn /* pow2 >= min(pre_topk, HWA) */, float *__restrict__ cand_boxes, float *__restrict__ cand_logit,
@@ -117,7 +117,17 @@ __global__ __launch_bounds__(RPN_THREADS) void rpn_select_decode_kernel(
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < HWA; i += RPN_THREADS) {
+        // eight loads in flight per thread (the sweep was one dependent load per iteration: latency-bound on one CU)
+        int i = tid;
+        for (; i + 7 * RPN_THREADS < HWA; i += 8 * RPN_THREADS) {
+            uint32_t kk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) kk[q] = key_at(i + q * RPN_THREADS);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if ((kk[q] & himask) == (prefix & himask)) atomicAdd(&hist[(kk[q] >> shift) & 255u], 1u);
+        }
+        for (; i < HWA; i += RPN_THREADS) {
             uint32_t k = key_at(i);
             if ((k & himask) == (prefix & himask)) atomicAdd(&hist[(k >> shift) & 255u], 1u);
         }
@@ -233,13 +243,45 @@ __global__ __launch_bounds__(RPN_THREADS) void rpn_select_decode_kernel(
     if (tid == 0) cand_count[n] = K;
 }
 
+__global__ __launch_bounds__(RPN_THREADS) void rpn_select_decode_kernel(
+    const float *__restrict__ logits, int ld_logits, const float *__restrict__ deltas, int ld_deltas, int Hf, int Wf,
+    int A, const float *__restrict__ cell_anchors, const int32_t *__restrict__ image_hw, DecodeCfg cfg, int pre_topk,
+    int sortn, float *__restrict__ cand_boxes, float *__restrict__ cand_logit, int32_t *__restrict__ cand_valid,
+    int32_t *__restrict__ cand_count, int32_t *__restrict__ nonfinite) {
+    rpn_select_decode_body(logits, ld_logits, deltas, ld_deltas, Hf, Wf, A, cell_anchors, image_hw, cfg, pre_topk, sortn, cand_boxes, cand_logit,
+                           cand_valid, cand_count, nonfinite);
+}
+
+// Every level of a pyramid in ONE launch (grid = images x levels): a level's selection is one workgroup per image, so five launches of
+// N workgroups one after the other left most of the chip idle (FPN detector at 32 images: 5 x 232 us; round 3).
+constexpr int RPN_SEL_LEVELS = 6;
+struct SelectLevels {
+    const float *logits[RPN_SEL_LEVELS], *deltas[RPN_SEL_LEVELS], *cell_anchors[RPN_SEL_LEVELS];
+    int ld_logits[RPN_SEL_LEVELS], ld_deltas[RPN_SEL_LEVELS], Hf[RPN_SEL_LEVELS], Wf[RPN_SEL_LEVELS], stride[RPN_SEL_LEVELS], sortn[RPN_SEL_LEVELS];
+    float *cand_boxes[RPN_SEL_LEVELS], *cand_logit[RPN_SEL_LEVELS];
+    int32_t *cand_valid[RPN_SEL_LEVELS], *cand_count[RPN_SEL_LEVELS];
+};
+__global__ __launch_bounds__(RPN_THREADS) void rpn_select_decode_levels_kernel(SelectLevels sl, int A, const int32_t *__restrict__ image_hw,
+                                                                               DecodeCfg cfg, int pre_topk, int32_t *__restrict__ nonfinite) {
+    const int l = blockIdx.y;
+    cfg.stride = sl.stride[l];
+    rpn_select_decode_body(sl.logits[l], sl.ld_logits[l], sl.deltas[l], sl.ld_deltas[l], sl.Hf[l], sl.Wf[l], A, sl.cell_anchors[l], image_hw, cfg,
+                           pre_topk, sl.sortn[l], sl.cand_boxes[l], sl.cand_logit[l], sl.cand_valid[l], sl.cand_count[l], nonfinite);
+}
+
 // ---------------------------------------------------------------------------
 // mask[n][i][cb] bit b set <=> j = cb*64+b > i and IoU(box_i, box_j) > thr.  grid (cb, rb, n), cb >= rb only.
+// Two-phase use (launch_nms below): phase A computes only the leading `lead` x `lead` blocks -- the greedy sweep stops at the
+// post-NMS cap, and the boxes behind the one that reaches it are never looked at; phase B (skip_lead = lead, done = the sweep's
+// per-image flag) fills in the rest for the images whose sweep ran out of phase A's rows, and returns at once for the others.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, const int32_t *__restrict__ counts,
                                                       int cap, int nwords, double thr,
-                                                      unsigned long long *__restrict__ mask) {
+                                                      unsigned long long *__restrict__ mask, int skip_lead,
+                                                      const int32_t *__restrict__ done) {
     const int cb = blockIdx.x, rb = blockIdx.y, n = blockIdx.z;
     if (cb < rb) return;
+    if (done && done[n]) return;
+    if (cb < skip_lead) return;                 // (rb <= cb: the block lies in the part phase A computed)
     const int cnt = counts[n];
     if (rb * 64 >= cnt || cb * 64 >= cnt) return;
     __shared__ float cbx[64][4];
@@ -281,11 +323,14 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const unsigned long long 
                                                        const int32_t *__restrict__ valid /* [n][cap] or null */,
                                                        const int32_t *__restrict__ counts, int cap, int nwords,
                                                        int max_keep, int32_t *__restrict__ keep_idx,
-                                                       int32_t *__restrict__ keep_count) {
+                                                       int32_t *__restrict__ keep_count, int max_chunks /* <= 0: all */,
+                                                       int32_t *__restrict__ done /* phase A writes, phase B reads; or null */) {
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int cnt = counts[n];
-    const int nw = (cnt + 63) >> 6;
+    const int nw_all = (cnt + 63) >> 6;
+    if (max_chunks <= 0 && done && done[n]) return;          // phase B: phase A's sweep was complete for this image
+    const int nw = max_chunks > 0 && max_chunks < nw_all ? max_chunks : nw_all;     // words (64-box chunks) this sweep may touch
     const unsigned long long *mk = mask + (long)n * cap * nwords;
     __shared__ unsigned long long sh_cur, sh_kept;
     __shared__ int sh_total;
@@ -358,7 +403,11 @@ __global__ __launch_bounds__(128) void nms_scan_kernel(const unsigned long long 
         }
         __syncthreads();
     }
-    if (tid == 0) keep_count[n] = total;
+    if (tid == 0) {
+        keep_count[n] = total;
+        // phase A: complete if the cap was reached or every box was swept (then phase B has nothing to add)
+        if (max_chunks > 0 && done) done[n] = (total >= max_keep || nw >= nw_all) ? 1 : 0;
+    }
 }
 
 // proposals out: boxes [n][R][4], logits [n][R], rois [n*R][5] (batch index + box; zero box beyond count)
@@ -562,9 +611,41 @@ static RpnWs carve_rpn_ws(void *base, int N, int pre, int post) {
     w.cand_count = (int32_t *)take((size_t)N * sizeof(int32_t));
     w.mask = (unsigned long long *)take((size_t)N * pre * nwords * 8);
     w.keep_idx = (int32_t *)take((size_t)N * (post > pre ? post : pre) * sizeof(int32_t));
-    w.keep_count = (int32_t *)take((size_t)N * sizeof(int32_t));
+    w.keep_count = (int32_t *)take((size_t)2 * N * sizeof(int32_t));          // [N] counts, [N] phase-A-complete flags (launch_nms)
     w.total = off;
     return w;
+}
+
+// Greedy NMS of N images' sorted candidates (boxes [N][cap][4], counts [N]): suppression masks + sweep, in two phases.  The sweep stops
+// at `max_keep` kept boxes, so only the boxes ahead of the one that reaches the cap matter: on the bench's input the 300th kept
+// proposal is the ~400th of 6000 candidates, and the full 6000 x 6000 mask was 474 us of IoU tests per batch for a sweep that read 0.5 %
+// of it.  Phase A: the leading `lead` boxes (2 x max_keep, at least 1024) -- mask blocks and sweep; phase B, for the images whose sweep
+// ran out of rows before reaching the cap: the rest of the mask and the sweep again from the start (greedy NMS is causal, so phase A's
+// result is exact whenever it completes).  No host round trip: phase B's workgroups look at a per-image flag and leave.
+static int launch_nms(const float *boxes, const int32_t *valid, const int32_t *counts, int N, int cap, int nb /* 64-box blocks in use */,
+                      double thr, int max_keep, unsigned long long *mask, int32_t *keep_idx, int32_t *keep_count, int32_t *done,
+                      hipStream_t s) {
+    const int nwords = ceil_div(cap, 64);
+    const char *e = getenv("VK_NMS_LEAD");                    // boxes of phase A; "0": one phase (A/B switch and tests; re-read per call)
+    int lead = e ? atoi(e) : (2 * max_keep > 1024 ? 2 * max_keep : 1024);
+    const int na = ceil_div(lead, 64);
+    if ((e && lead <= 0) || na >= nb || !done) {
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, N), dim3(64), 0, s, boxes, counts, cap, nwords, thr, mask, 0, (const int32_t *)nullptr);
+        VK_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, mask, valid, counts, cap, nwords, max_keep, keep_idx, keep_count, 0,
+                           (int32_t *)nullptr);
+        VK_CHECK_HIP(hipGetLastError());
+        return VK_OK;
+    }
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(na, na, N), dim3(64), 0, s, boxes, counts, cap, nwords, thr, mask, 0, (const int32_t *)nullptr);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, mask, valid, counts, cap, nwords, max_keep, keep_idx, keep_count, na, done);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, N), dim3(64), 0, s, boxes, counts, cap, nwords, thr, mask, na, (const int32_t *)done);
+    VK_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, mask, valid, counts, cap, nwords, max_keep, keep_idx, keep_count, 0, done);
+    VK_CHECK_HIP(hipGetLastError());
+    return VK_OK;
 }
 
 }  // namespace vk
@@ -614,14 +695,9 @@ int vk_rpn_proposals(const float *logits, int ld_logits, const float *deltas, in
                        Hf, Wf, A, cell_anchors, image_hw, cfg, pre_topk, sortn, w.cand_boxes, w.cand_logit, w.cand_valid,
                        w.cand_count, nonfinite_flag);
     VK_CHECK_HIP(hipGetLastError());
-    const int nwords = ceil_div(pre_topk, 64);
     const int nb = ceil_div(K, 64);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, N), dim3(64), 0, s, w.cand_boxes, w.cand_count, pre_topk, nwords,
-                       nms_thresh, w.mask);
-    VK_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, w.mask, w.cand_valid, w.cand_count, pre_topk, nwords,
-                       post_topk, w.keep_idx, w.keep_count);
-    VK_CHECK_HIP(hipGetLastError());
+    VK_TRY(launch_nms(w.cand_boxes, w.cand_valid, w.cand_count, N, pre_topk, nb, nms_thresh, post_topk, w.mask, w.keep_idx, w.keep_count,
+                      w.keep_count + N, s));
     hipLaunchKernelGGL(rpn_gather_kernel, dim3(N), dim3(256), 0, s, w.cand_boxes, w.cand_logit, pre_topk, w.keep_idx,
                        w.keep_count, post_topk, out_boxes, out_logits, out_counts);
     VK_CHECK_HIP(hipGetLastError());
@@ -659,7 +735,7 @@ static MlWs carve_ml_ws(void *base, int N, int levels, int pre, int post) {
     w.m_count = (int32_t *)take((size_t)N * sizeof(int32_t));
     w.mask = (unsigned long long *)take((size_t)N * cap * nwords * 8);
     w.keep_idx = (int32_t *)take((size_t)N * post * sizeof(int32_t));
-    w.keep_count = (int32_t *)take((size_t)N * sizeof(int32_t));
+    w.keep_count = (int32_t *)take((size_t)2 * N * sizeof(int32_t));          // [N] counts, [N] phase-A-complete flags (launch_nms)
     w.total = off;
     return w;
 }
@@ -686,6 +762,8 @@ int vk_rpn_proposals_multilevel(const float *const *logits, const int32_t *ld_lo
     if (!attr_set) {
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rpn_select_decode_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, RPN_MAX_PRE * 8 + 2048));
+        VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rpn_select_decode_levels_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RPN_MAX_PRE * 8 + 2048));
         VK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rpn_merge_levels_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, RPN_MAX_PRE * 8 + 256));
         attr_set = true;
@@ -694,38 +772,50 @@ int vk_rpn_proposals_multilevel(const float *const *logits, const int32_t *ld_lo
     memset(&lc, 0, sizeof(lc));
     lc.levels = levels;
     lc.pre = pre_topk;
+    static_assert(RPN_SEL_LEVELS >= RPN_MAX_LEVELS, "one slot per level");
+    SelectLevels sl;
+    memset(&sl, 0, sizeof(sl));
+    int max_sortn = 2;
     for (int l = 0; l < levels; ++l) {
         const long HWA = (long)Hs[l] * Ws[l] * A;
         VK_REQUIRE(Hs[l] > 0 && Ws[l] > 0 && HWA < (1L << 31), VK_EINVAL, "rpn_ml: level %d has a bad size", l);
         const int K = (int)(pre_topk < HWA ? pre_topk : HWA);
-        const int sortn = next_pow2(K);
-        DecodeCfg cfg;
-        cfg.wx = bbox_weights4_host[0];
-        cfg.wy = bbox_weights4_host[1];
-        cfg.ww = bbox_weights4_host[2];
-        cfg.wh = bbox_weights4_host[3];
-        cfg.scale_clamp = (float)log(1000.0 / 16.0);
-        cfg.min_size = min_size;
-        cfg.stride = strides[l];
-        cfg.offset = offset;
-        hipLaunchKernelGGL(rpn_select_decode_kernel, dim3(N), dim3(RPN_THREADS), (size_t)sortn * 8 + 2048, s, logits[l], ld_logits[l], deltas[l],
-                           ld_deltas[l], Hs[l], Ws[l], A, cell_anchors[l], image_hw, cfg, pre_topk, sortn, w.lv[l].cand_boxes,
-                           w.lv[l].cand_logit, w.lv[l].cand_valid, w.lv[l].cand_count, nonfinite_flag);
-        VK_CHECK_HIP(hipGetLastError());
+        sl.logits[l] = logits[l];
+        sl.deltas[l] = deltas[l];
+        sl.cell_anchors[l] = cell_anchors[l];
+        sl.ld_logits[l] = ld_logits[l];
+        sl.ld_deltas[l] = ld_deltas[l];
+        sl.Hf[l] = Hs[l];
+        sl.Wf[l] = Ws[l];
+        sl.stride[l] = strides[l];
+        sl.sortn[l] = next_pow2(K);
+        max_sortn = sl.sortn[l] > max_sortn ? sl.sortn[l] : max_sortn;
+        sl.cand_boxes[l] = w.lv[l].cand_boxes;
+        sl.cand_logit[l] = w.lv[l].cand_logit;
+        sl.cand_valid[l] = w.lv[l].cand_valid;
+        sl.cand_count[l] = w.lv[l].cand_count;
         lc.boxes[l] = w.lv[l].cand_boxes;
         lc.logit[l] = w.lv[l].cand_logit;
         lc.valid[l] = w.lv[l].cand_valid;
         lc.count[l] = w.lv[l].cand_count;
     }
+    DecodeCfg cfg;
+    cfg.wx = bbox_weights4_host[0];
+    cfg.wy = bbox_weights4_host[1];
+    cfg.ww = bbox_weights4_host[2];
+    cfg.wh = bbox_weights4_host[3];
+    cfg.scale_clamp = (float)log(1000.0 / 16.0);
+    cfg.min_size = min_size;
+    cfg.stride = 0;                                  // per level, from sl.stride
+    cfg.offset = offset;
+    hipLaunchKernelGGL(rpn_select_decode_levels_kernel, dim3(N, levels), dim3(RPN_THREADS), (size_t)max_sortn * 8 + 2048, s, sl, A, image_hw, cfg,
+                       pre_topk, nonfinite_flag);
+    VK_CHECK_HIP(hipGetLastError());
     const int cap = levels * pre_topk, sortn = next_pow2(cap), nwords = ceil_div(cap, 64);
     hipLaunchKernelGGL(rpn_merge_levels_kernel, dim3(N), dim3(RPN_THREADS), (size_t)sortn * 8 + 256, s, lc, cap, sortn, w.m_boxes, w.m_shift,
                        w.m_logit, w.m_count);
     VK_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, N), dim3(64), 0, s, w.m_shift, w.m_count, cap, nwords, nms_thresh, w.mask);
-    VK_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(N), dim3(128), 0, s, w.mask, (const int32_t *)nullptr, w.m_count, cap, nwords, post_topk,
-                       w.keep_idx, w.keep_count);
-    VK_CHECK_HIP(hipGetLastError());
+    VK_TRY(launch_nms(w.m_shift, nullptr, w.m_count, N, cap, nwords, nms_thresh, post_topk, w.mask, w.keep_idx, w.keep_count, w.keep_count + N, s));
     hipLaunchKernelGGL(rpn_gather_kernel, dim3(N), dim3(256), 0, s, w.m_boxes, w.m_logit, cap, w.keep_idx, w.keep_count, post_topk, out_boxes,
                        out_logits, out_counts);
     VK_CHECK_HIP(hipGetLastError());
@@ -766,11 +856,8 @@ int vk_nms(const float *boxes, const float *scores, int n, double thresh, int64_
                        sorted_boxes, order, cnt);
     VK_CHECK_HIP(hipGetLastError());
     const int nwords = ceil_div(n, 64);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, 1), dim3(64), 0, s, sorted_boxes, cnt, n, nwords, thresh, w.mask);
-    VK_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(128), 0, s, w.mask, (const int32_t *)nullptr, cnt, n, nwords, n,
-                       w.keep_idx, w.keep_count);
-    VK_CHECK_HIP(hipGetLastError());
+    // (max_keep = n: one phase unless VK_NMS_LEAD forces a short phase A -- which is how the tests reach phase B)
+    VK_TRY(launch_nms(sorted_boxes, nullptr, cnt, 1, n, nwords, thresh, n, w.mask, w.keep_idx, w.keep_count, w.keep_count + 1, s));
     hipLaunchKernelGGL(nms_emit_kernel, dim3(1), dim3(256), 0, s, order, w.keep_idx, w.keep_count, keep_out, count_out);
     VK_CHECK_HIP(hipGetLastError());
     return VK_OK;
