@@ -46,6 +46,7 @@ struct DecodeCfg {
     float min_size;
     int stride;
     float offset;
+    int stop;                // tools build only (VK_RPN_STOP): leave after the radix select (1), the compaction (2), the sort (3) -- timing only
 };
 
 // Box2BoxTransform.apply_deltas for one box (frcnn.py:559-583), fp32, reference op order.
@@ -147,6 +148,9 @@ __device__ __forceinline__ void rpn_select_decode_body(
         __syncthreads();
     }
     const uint32_t T = prefix;   // threshold key; `need` of the keys equal to T are taken, lowest index first
+#ifdef VK_ABLATION
+    if (cfg.stop == 1) return;
+#endif
 
     // ---- compaction in flat-index order ----
     for (int i = tid; i < sortn; i += RPN_THREADS) skey[i] = ~0ull;
@@ -195,6 +199,9 @@ __device__ __forceinline__ void rpn_select_decode_body(
         __syncthreads();
     }
 
+#ifdef VK_ABLATION
+    if (cfg.stop == 2) return;
+#endif
     // ---- bitonic sort (ascending composite key == score desc, index asc) ----
     for (int k2 = 2; k2 <= sortn; k2 <<= 1) {
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -213,6 +220,9 @@ __device__ __forceinline__ void rpn_select_decode_body(
         }
     }
 
+#ifdef VK_ABLATION
+    if (cfg.stop == 3) return;
+#endif
     // ---- decode + clip + size filter of the K sorted candidates ----
     const float img_h = (float)image_hw[2 * n], img_w = (float)image_hw[2 * n + 1];
     bool bad = false;
@@ -684,6 +694,10 @@ int vk_rpn_proposals(const float *logits, int ld_logits, const float *deltas, in
     cfg.min_size = min_size;
     cfg.stride = stride;
     cfg.offset = offset;
+    cfg.stop = 0;
+#ifdef VK_ABLATION
+    if (const char *e = getenv("VK_RPN_STOP")) cfg.stop = atoi(e);
+#endif
     const size_t smem = (size_t)sortn * 8 + 2048;
     static bool attr_set = false;
     if (!attr_set) {
@@ -808,6 +822,7 @@ int vk_rpn_proposals_multilevel(const float *const *logits, const int32_t *ld_lo
     cfg.min_size = min_size;
     cfg.stride = 0;                                  // per level, from sl.stride
     cfg.offset = offset;
+    cfg.stop = 0;
     hipLaunchKernelGGL(rpn_select_decode_levels_kernel, dim3(N, levels), dim3(RPN_THREADS), (size_t)max_sortn * 8 + 2048, s, sl, A, image_hw, cfg,
                        pre_topk, nonfinite_flag);
     VK_CHECK_HIP(hipGetLastError());
